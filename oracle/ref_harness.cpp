@@ -1,0 +1,275 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Seed-level driver around the REAL reference (compiled from /root/reference by oracle/Makefile `make ref`).
+// The reference prints only SAM, so this harness calls its seeding functions directly and dumps, per read,
+// the sorted mem list and the SAL seed list, plus the reference's own counters.  Two paths are run and
+// compared read by read:
+//   path A (BWA-MEM, uncached)  : bwt_smem1 / bwt_seed_strategy1 (FM_index/bwt.h:123-126) driven by the three
+//                                 loops of mem_collect_intv (mapping/bwamem.c:218-272; that function is static)
+//   path B (CompSeed, SST cache): collect_mem_with_sst / tem_forward_sst (mapping/comp_seed.cpp:67,141) driven by
+//                                 the loops of seed_and_extend (mapping/comp_seed.cpp:2255-2302), SSTs cleared
+//                                 every BATCH_SIZE reads (comp_seed.cpp:2254)
+// SAL follows comp_seed.cpp:2306-2347 (slot sampling, per-batch dedup, bwt_sa).
+//
+// Output file (little endian):
+//   char magic[8]="CSGOLD1"; u64 n_reads, n_mems, n_seeds, bwt_queries, bwt_calls, sal_queries, sal_calls, n_diff_AB
+//   u64 mem_off[n_reads+1];  {u64 x0,x1,x2,info} mems[n_mems]
+//   u64 seed_off[n_reads+1]; {i64 rbeg; i32 qbeg; i32 len} seeds[n_seeds]
+// With --prim FILE N SEED it also dumps known-answer vectors for the primitives (format below at dump_prims).
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "bwalib/bwa.h"
+#include "FM_index/bwt.h"
+#include "FM_index/bntseq.h"
+#include "mapping/comp_seed.h"
+
+thread_aux_t tprof; // comp_seed.cpp:22 declares it extern
+
+int collect_mem_with_sst(const uint8_t *seq, int len, int pivot, int min_hits, thread_aux_t &aux);
+int tem_forward_sst(const mem_opt_t *opt, const uint8_t *seq, int len, int start, bwtintv_t *mem, thread_aux_t &aux);
+
+static bool by_info(const bwtintv_t &a, const bwtintv_t &b) { return a.info < b.info; }
+
+// mapping/bwamem.c:218-272 replayed with the public bwt.h entry points
+static void path_bwamem(const mem_opt_t *opt, const bwt_t *bwt, int len, const uint8_t *seq,
+                        std::vector<bwtintv_t> &out, bwtintv_v *tmpv[2], bwtintv_v *mem1)
+{
+	int x = 0;
+	int split_len = (int)(opt->min_seed_len * opt->split_factor + .499); // float product, as bwamem.c:223
+	out.clear();
+	while (x < len) {
+		if (seq[x] < 4) {
+			x = bwt_smem1(bwt, len, seq, x, 1, mem1, tmpv);
+			for (size_t i = 0; i < mem1->n; ++i) {
+				bwtintv_t *p = &mem1->a[i];
+				int slen = (uint32_t)p->info - (p->info >> 32);
+				if (slen >= opt->min_seed_len) out.push_back(*p);
+			}
+		} else ++x;
+	}
+	size_t old_n = out.size();
+	for (size_t k = 0; k < old_n; ++k) {
+		bwtintv_t p = out[k];
+		int start = p.info >> 32, end = (int32_t)p.info;
+		if (end - start < split_len || p.x[2] > (uint64_t)opt->split_width) continue;
+		bwt_smem1(bwt, len, seq, (start + end) >> 1, p.x[2] + 1, mem1, tmpv);
+		for (size_t i = 0; i < mem1->n; ++i)
+			if ((uint32_t)mem1->a[i].info - (mem1->a[i].info >> 32) >= (uint32_t)opt->min_seed_len)
+				out.push_back(mem1->a[i]);
+	}
+	if (opt->max_mem_intv > 0) {
+		x = 0;
+		while (x < len) {
+			if (seq[x] < 4) {
+				bwtintv_t m;
+				x = bwt_seed_strategy1(bwt, len, seq, x, opt->min_seed_len, opt->max_mem_intv, &m);
+				if (m.x[2] > 0) out.push_back(m);
+			} else ++x;
+		}
+	}
+	std::stable_sort(out.begin(), out.end(), by_info);
+}
+
+// mapping/comp_seed.cpp:2262-2301 replayed on one read
+static void path_compseed(const mem_opt_t *opt, int len, const uint8_t *seq, thread_aux_t &aux, std::vector<bwtintv_t> &match)
+{
+	match.clear();
+	for (int j = 0; j < len; ) {
+		j = collect_mem_with_sst(seq, len, j, 1, aux);
+		for (const auto &m : aux.super_mem)
+			if ((int)m.info - (int)(m.info >> 32) >= opt->min_seed_len) match.push_back(m);
+	}
+	int old_n = (int)match.size();
+	for (int j = 0; j < old_n; j++) {
+		const bwtintv_t p = match[j];
+		int beg = p.info >> 32, end = (int)p.info;
+		if (end - beg < (int)(1.0 * opt->min_seed_len * opt->split_factor + .499) or p.x[2] > (uint64_t)opt->split_width) continue;
+		collect_mem_with_sst(seq, len, (beg + end) / 2, p.x[2] + 1, aux);
+		for (const auto &m : aux.super_mem)
+			if ((int)m.info - (int)(m.info >> 32) >= opt->min_seed_len) match.push_back(m);
+	}
+	if (opt->max_mem_intv > 0) {
+		for (int j = 0; j < len; ) {
+			if (seq[j] < 4) {
+				bwtintv_t m;
+				j = tem_forward_sst(opt, seq, len, j, &m, aux);
+				if (m.x[2] > 0) match.push_back(m);
+			} else j++;
+		}
+	}
+	std::sort(match.begin(), match.end(), by_info);
+}
+
+struct seed_out_t { int64_t rbeg; int32_t qbeg, len; };
+
+static uint64_t splitmix(uint64_t &s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+// Known-answer vectors for the primitives.  File:
+//   char magic[8]="CSPRIM1"; u64 n_occ4, n_2occ4, n_ext, n_sa
+//   occ4 : n x {u64 k; u64 cnt[4]}                              bwt_occ4   (FM_index/bwt.c:169)
+//   2occ4: n x {u64 k,l; u64 cntk[4], cntl[4]}                  bwt_2occ4  (bwt.c:189)
+//   ext  : n x {u64 x0,x1,x2; u64 is_back; u64 ok[4][3]}        bwt_extend (bwt.c:262)
+//   sa   : n x {u64 k; u64 sa}                                  bwt_sa     (bwt.c:86)
+static void dump_prims(const bwt_t *bwt, const char *fn, long n, uint64_t seed, const std::vector<bwtintv_t> &pool)
+{
+	FILE *fp = fopen(fn, "wb");
+	if (!fp) { perror(fn); exit(1); }
+	uint64_t hdr[4] = {(uint64_t)n, (uint64_t)n, (uint64_t)n, (uint64_t)n};
+	fwrite("CSPRIM1", 1, 8, fp); fwrite(hdr, 8, 4, fp);
+	uint64_t N = bwt->seq_len, P = bwt->primary;
+	auto pick_k = [&](long i) -> uint64_t {
+		switch (i) { // edge rows first
+			case 0: return (uint64_t)-1; case 1: return 0; case 2: return P; case 3: return P - 1; case 4: return P + 1;
+			case 5: return N; case 6: return N - 1; case 7: return 127; case 8: return 128; case 9: return 129;
+			default: return splitmix(seed) % (N + 1);
+		}
+	};
+	for (long i = 0; i < n; i++) {
+		uint64_t rec[5]; rec[0] = pick_k(i);
+		bwt_occ4(bwt, rec[0], rec + 1);
+		fwrite(rec, 8, 5, fp);
+	}
+	for (long i = 0; i < n; i++) {
+		uint64_t rec[10];
+		uint64_t k = pick_k(i);
+		uint64_t span = (i & 1) ? splitmix(seed) % 300 : splitmix(seed) % (N + 1);
+		uint64_t l = (k == (uint64_t)-1) ? splitmix(seed) % (N + 1) : k + span;
+		if (l > N) l = N;
+		rec[0] = k; rec[1] = l;
+		bwt_2occ4(bwt, k, l, rec + 2, rec + 6);
+		fwrite(rec, 8, 10, fp);
+	}
+	for (long i = 0; i < n; i++) {
+		bwtintv_t ik, ok[4];
+		if (!pool.empty() && (i % 3) != 0) ik = pool[splitmix(seed) % pool.size()];
+		else { int c0 = (int)(splitmix(seed) & 3); bwt_set_intv(bwt, c0, ik); } // macro evaluates its argument 4x
+		uint64_t is_back = splitmix(seed) & 1;
+		memset(ok, 0, sizeof(ok));
+		bwt_extend(bwt, &ik, ok, (int)is_back);
+		uint64_t rec[16] = {ik.x[0], ik.x[1], ik.x[2], is_back};
+		for (int c = 0; c < 4; c++) for (int j = 0; j < 3; j++) rec[4 + c * 3 + j] = ok[c].x[j];
+		fwrite(rec, 8, 16, fp);
+	}
+	for (long i = 0; i < n; i++) {
+		uint64_t rec[2];
+		uint64_t k = pick_k(i + 1); // k = -1 is not a valid row
+		rec[0] = k; rec[1] = bwt_sa(bwt, k);
+		fwrite(rec, 8, 2, fp);
+	}
+	fclose(fp);
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 4) {
+		fprintf(stderr, "usage: ref_dump <idx prefix> <reads.txt> <out.bin> [-k INT] [-r FLOAT] [-y INT] [-c INT] [-s INT] [-B batch] [--prim FILE N SEED]\n");
+		return 1;
+	}
+	mem_opt_t *opt = mem_opt_init();
+	int batch = BATCH_SIZE;
+	const char *prim_fn = 0; long prim_n = 0; uint64_t prim_seed = 1;
+	for (int i = 4; i < argc; i++) {
+		std::string a = argv[i];
+		if (a == "-k") opt->min_seed_len = atoi(argv[++i]);
+		else if (a == "-r") opt->split_factor = atof(argv[++i]);
+		else if (a == "-y") opt->max_mem_intv = atol(argv[++i]);
+		else if (a == "-c") opt->max_occ = atoi(argv[++i]);
+		else if (a == "-s") opt->split_width = atoi(argv[++i]);
+		else if (a == "-B") batch = atoi(argv[++i]);
+		else if (a == "--prim") { prim_fn = argv[++i]; prim_n = atol(argv[++i]); prim_seed = strtoull(argv[++i], 0, 10); }
+		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
+	}
+	if (batch < 1 || batch > BATCH_SIZE) { fprintf(stderr, "batch must be in [1,%d]\n", BATCH_SIZE); return 1; }
+	bwa_verbose = 1;
+	bwaidx_t *idx = bwa_idx_load(argv[1], BWA_IDX_BWT);
+	if (!idx) { fprintf(stderr, "cannot load index %s\n", argv[1]); return 1; }
+	const bwt_t *bwt = idx->bwt;
+
+	std::vector<std::string> reads;
+	{
+		FILE *fp = fopen(argv[2], "r");
+		if (!fp) { perror(argv[2]); return 1; }
+		std::string cur; int ch;
+		while ((ch = fgetc(fp)) != EOF) { if (ch == '\n') { reads.push_back(cur); cur.clear(); } else cur.push_back((char)ch); }
+		if (!cur.empty()) reads.push_back(cur);
+		fclose(fp);
+	}
+	size_t n = reads.size();
+
+	thread_aux_t aux;
+	aux.forward_sst = new SST(bwt);
+	aux.backward_sst = new SST(bwt);
+	bwtintv_v tv0 = {0, 0, 0}, tv1 = {0, 0, 0}, mem1 = {0, 0, 0};
+	bwtintv_v *tmpv[2] = {&tv0, &tv1};
+
+	std::vector<uint64_t> mem_off(n + 1, 0), seed_off(n + 1, 0);
+	std::vector<bwtintv_t> mems, A, B;
+	std::vector<seed_out_t> seeds;
+	uint64_t n_diff = 0, sal_queries = 0, sal_calls = 0, bwt_calls = 0;
+
+	for (size_t b0 = 0; b0 < n; b0 += batch) {
+		size_t b1 = std::min(n, b0 + (size_t)batch);
+		aux.forward_sst->clear(); aux.backward_sst->clear();
+		for (size_t r = b0; r < b1; r++) {
+			std::vector<uint8_t> seq(reads[r].size() + 1, 4);
+			int len = (int)reads[r].size();
+			for (int j = 0; j < len; j++) seq[j] = nst_nt4_table[(uint8_t)reads[r][j]];
+			path_bwamem(opt, bwt, len, seq.data(), A, tmpv, &mem1);
+			path_compseed(opt, len, seq.data(), aux, B);
+			bool same = A.size() == B.size();
+			for (size_t i = 0; same && i < A.size(); i++)
+				same = A[i].x[0] == B[i].x[0] && A[i].x[1] == B[i].x[1] && A[i].x[2] == B[i].x[2] && A[i].info == B[i].info;
+			if (!same) n_diff++;
+			mems.insert(mems.end(), B.begin(), B.end());
+			mem_off[r + 1] = mems.size();
+		}
+		bwt_calls += aux.forward_sst->bwt_call + aux.backward_sst->bwt_call;
+		// SAL, comp_seed.cpp:2306-2347
+		std::vector<sal_request_t> uniq;
+		size_t s0 = seeds.size();
+		for (size_t r = b0; r < b1; r++) {
+			for (uint64_t i = mem_off[r]; i < mem_off[r + 1]; i++) {
+				const bwtintv_t &m = mems[i];
+				uint64_t step = m.x[2] > (uint64_t)opt->max_occ ? m.x[2] / opt->max_occ : 1;
+				for (uint64_t k = 0, count = 0; k < m.x[2] && count < (uint64_t)opt->max_occ; k += step, count++) {
+					seed_out_t s; s.qbeg = m.info >> 32; s.len = (int)m.info - (int)(m.info >> 32); s.rbeg = m.x[0] + k;
+					seeds.push_back(s);
+					uniq.emplace_back(sal_request_t(m.x[0] + k));
+					sal_queries++;
+				}
+			}
+			seed_off[r + 1] = seeds.size();
+		}
+		std::sort(uniq.begin(), uniq.end());
+		size_t sz = 0;
+		for (size_t i = 0; i < uniq.size(); i++) if (i == 0 or uniq[i - 1].que_location != uniq[i].que_location) uniq[sz++] = uniq[i];
+		uniq.resize(sz);
+		for (size_t i = s0; i < seeds.size(); i++) {
+			auto k = std::lower_bound(uniq.begin(), uniq.end(), sal_request_t(seeds[i].rbeg));
+			if (k->coordinate == (uint64_t)-1) { k->coordinate = bwt_sa(bwt, seeds[i].rbeg); sal_calls++; }
+			seeds[i].rbeg = k->coordinate;
+		}
+	}
+
+	FILE *fp = fopen(argv[3], "wb");
+	if (!fp) { perror(argv[3]); return 1; }
+	uint64_t hdr[8] = {n, mems.size(), seeds.size(), (uint64_t)aux.bwt_query_times, bwt_calls, sal_queries, sal_calls, n_diff};
+	fwrite("CSGOLD1", 1, 8, fp);
+	fwrite(hdr, 8, 8, fp);
+	fwrite(mem_off.data(), 8, n + 1, fp);
+	fwrite(mems.data(), sizeof(bwtintv_t), mems.size(), fp);
+	fwrite(seed_off.data(), 8, n + 1, fp);
+	fwrite(seeds.data(), sizeof(seed_out_t), seeds.size(), fp);
+	fclose(fp);
+	fprintf(stderr, "[ref_dump] reads=%zu mems=%zu seeds=%zu bwt_queries=%ld bwt_calls=%lu sal_queries=%lu sal_calls=%lu diffAB=%lu\n",
+	        n, mems.size(), seeds.size(), aux.bwt_query_times, (unsigned long)bwt_calls, (unsigned long)sal_queries, (unsigned long)sal_calls, (unsigned long)n_diff);
+	if (prim_fn) dump_prims(bwt, prim_fn, prim_n, prim_seed, mems);
+	return n_diff ? 2 : 0;
+}

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only where /root/reference exists (the build container): it needs oracle/_ref/bwaidx and
+oracle/_ref/ref_dump, which `make -C oracle ref` compiles from the reference sources in place.
+The GPU box never runs this script; it only reads the files written here.
+
+What is produced (all data, no reference source text):
+  g1/ref.fa.gz                       synthetic 2-contig genome with planted repeats and an N run
+  g1/ref.{bwt,sa,pac,ann,amb}        index built by the reference's own `bwaidx` (index_main.c:257)
+  g1/<reads>.txt                     read sets, one read per line (CompSeed's reordered-reads format, main.cpp:36-58)
+  g1/<reads>.<params>.npz            per-read sorted mem lists + SAL seeds + reference counters (ref_harness.cpp)
+  g1/prims.npz                       known-answer vectors for bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_sa
+  MANIFEST.json                      md5 of every file + the harness stderr summary per run
+"""
+import gzip, hashlib, json, os, random, subprocess, sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+COMP = str.maketrans("ACGTNacgtn", "TGCANtgcan")
+
+
+def revcomp(s):
+    return s.translate(COMP)[::-1]
+
+
+def mutate(rng, s, p_sub):
+    r = list(s)
+    for i in range(len(r)):
+        if rng.random() < p_sub:
+            r[i] = rng.choice("ACGT")
+    return "".join(r)
+
+
+def make_genome(rng):
+    L = 200000
+    base = "".join(rng.choice("ACGT") for _ in range(L))
+    # segmental duplications (exact copies)
+    g = base[:50000] + base[1000:3000] + base[50000:120000] + base[1000:2500] + base[120000:]
+    # interspersed repeat family: 300-bp element, 40 copies, 3 % divergence
+    elem = "".join(rng.choice("ACGT") for _ in range(300))
+    g = list(g)
+    for _ in range(40):
+        p = rng.randrange(0, len(g) - 300)
+        g[p:p + 300] = mutate(rng, elem, 0.03)
+    g = "".join(g)
+    # tandem repeat: 23-bp unit x 700 copies -> k-mers with > 500 occurrences (max_occ sampling path)
+    unit = "".join(rng.choice("ACGT") for _ in range(23))
+    g = g[:150000] + unit * 700 + g[150000:]
+    # homopolymer / low-complexity stretch
+    g = g[:30000] + "A" * 120 + "AC" * 80 + g[30000:]
+    # an N run (bwaidx replaces it by lrand48 bases, bntseq.c:295)
+    g = g[:90000] + "N" * 57 + g[90000:]
+    half = len(g) // 2
+    return [("chr1", g[:half]), ("chr2", g[half:])], unit
+
+
+def write_fasta(path, contigs):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        for name, s in contigs:
+            f.write((">%s\n" % name).encode())
+            for i in range(0, len(s), 60):
+                f.write((s[i:i + 60] + "\n").encode())
+
+
+def sample_reads(rng, g, n, length, p_sub, p_n=0.002, sort=True, region=None, avoid=None):
+    lo, hi = region if region else (0, len(g) - length)
+    pos = []
+    while len(pos) < n:
+        p = rng.randrange(lo, max(lo + 1, hi))
+        if avoid and p + length > avoid[0] and p < avoid[1]:
+            continue  # keep the 700-copy tandem array out of the big sets (each hit costs 500 SAL seeds)
+        pos.append(p)
+    if sort:
+        pos.sort()
+    out = []
+    for p in pos:
+        r = mutate(rng, g[p:p + length].replace("N", "A"), p_sub)
+        if rng.random() < p_n and r:
+            r = list(r); r[rng.randrange(len(r))] = "N"; r = "".join(r)
+        if rng.random() < 0.5:
+            r = revcomp(r)
+        out.append(r)
+    return out
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def run(cmd, **kw):
+    print("+", " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd, check=False, capture_output=True, text=True, **kw)
+
+
+def parse_gold(path):
+    raw = open(path, "rb").read()
+    assert raw[:7] == b"CSGOLD1"
+    hdr = np.frombuffer(raw, dtype="<u8", count=8, offset=8)
+    n, n_mems, n_seeds = int(hdr[0]), int(hdr[1]), int(hdr[2])
+    off = 8 + 64
+    mem_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
+    mems = np.frombuffer(raw, dtype="<u8", count=4 * n_mems, offset=off).reshape(n_mems, 4); off += 32 * n_mems
+    seed_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
+    sd = np.frombuffer(raw, dtype=np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")]), count=n_seeds, offset=off)
+    return dict(counters=hdr.copy(), mem_off=mem_off.copy(), mems=mems.copy(), seed_off=seed_off.copy(),
+                seed_rbeg=sd["rbeg"].copy(), seed_qbeg=sd["qbeg"].copy(), seed_len=sd["len"].copy())
+
+
+def parse_prims(path):
+    raw = open(path, "rb").read()
+    assert raw[:7] == b"CSPRIM1"
+    n = np.frombuffer(raw, dtype="<u8", count=4, offset=8)
+    off = 8 + 32
+    out = {}
+    for name, cnt, w in (("occ4", int(n[0]), 5), ("occ2x4", int(n[1]), 10), ("ext", int(n[2]), 16), ("sa", int(n[3]), 2)):
+        out[name] = np.frombuffer(raw, dtype="<u8", count=cnt * w, offset=off).reshape(cnt, w).copy()
+        off += 8 * cnt * w
+    return out
+
+
+PARAM_SETS = {
+    # name -> harness flags.  "default" = mem_opt_init (comp_seed.cpp:26): -k 19 -r 1.5 -y 20 -c 500 -s 10
+    "default": [],
+    "r1.0": ["-r", "1.0"],
+    "y0": ["-y", "0"],
+    "k14": ["-k", "14"],
+    "c50s20": ["-c", "50", "-s", "20"],
+    "k25r2.5y5": ["-k", "25", "-r", "2.5", "-y", "5"],
+}
+
+
+def main():
+    if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
+        sys.exit("build the reference harness first: make -C oracle ref")
+    rng = random.Random(20261003)
+    d = os.path.join(HERE, "g1")
+    os.makedirs(d, exist_ok=True)
+    contigs, unit = make_genome(rng)
+    g = "".join(s for _, s in contigs)
+    fa = os.path.join(d, "ref.fa.gz")
+    write_fasta(fa, contigs)
+    manifest = {"runs": {}, "md5": {}}
+    r = run([os.path.join(REFBIN, "bwaidx"), "-p", os.path.join(d, "ref"), fa])
+    if r.returncode:
+        sys.exit(r.stderr)
+
+    sets = {}
+    tpos = g.find(unit * 3)
+    assert tpos > 0
+    tandem = (tpos, tpos + 23 * 700)
+    sets["main100"] = sample_reads(rng, g, 3000, 100, 0.01, avoid=tandem)
+    sets["sorted150"] = sample_reads(rng, g, 1500, 150, 0.005, p_n=0.0, avoid=tandem)
+    # repeat-rich reads: tandem array and the low-complexity stretch
+    rep = sample_reads(rng, g, 60, 100, 0.005, region=(max(0, tpos - 200), tpos + 23 * 700 + 100))
+    rep += sample_reads(rng, g, 60, 100, 0.01, region=(29900, 30400))
+    sets["repeat100"] = rep
+    # ragged set: empty reads, reads shorter than k, all-N, lower case, '-' and other IUPAC bytes, long reads
+    rag = ["", "A", "ACGT", "N" * 40, "", g[1000:1018], g[1000:1019], g[1000:1020], g[5000:5300].lower(),
+           g[7000:7100][:50] + "-" + g[7000:7100][51:], g[8000:8100][:30] + "RYK" + g[8000:8100][33:],
+           "N" + g[9000:9100], g[9000:9100] + "N", revcomp(g[12000:12700]), g[1000:3000][:1500]]
+    for _ in range(285):
+        ln = rng.choice([0, 5, 18, 19, 20, 27, 28, 29, 30, 36, 50, 75, 101, 151, 250])
+        rr = sample_reads(rng, g, 1, ln, rng.choice([0.0, 0.01, 0.05, 0.2]), p_n=0.05, sort=False) if ln else [""]
+        rag += rr
+    sets["ragged"] = rag
+    shuf = list(sets["main100"][:1000]); rng.shuffle(shuf)
+    sets["shuffled100"] = shuf
+
+    runs = [("main100", p) for p in PARAM_SETS] + [("sorted150", "default"), ("sorted150", "r1.0"),
+            ("repeat100", "default"), ("repeat100", "c50s20"), ("ragged", "default"), ("ragged", "k14"),
+            ("ragged", "y0"), ("shuffled100", "default")]
+    for name, rd in sets.items():
+        with open(os.path.join(d, name + ".txt"), "w") as f:
+            f.write("".join(x + "\n" for x in rd))
+    tmp = os.path.join(d, "_tmp.bin"); ptmp = os.path.join(d, "_prim.bin")
+    for i, (name, pname) in enumerate(runs):
+        cmd = [os.path.join(REFBIN, "ref_dump"), os.path.join(d, "ref"), os.path.join(d, name + ".txt"), tmp] + PARAM_SETS[pname]
+        if i == 0:
+            cmd += ["--prim", ptmp, "4000", "7"]
+        r = run(cmd)
+        if r.returncode:
+            sys.exit("ref_dump failed (%d): %s" % (r.returncode, r.stderr))
+        gold = parse_gold(tmp)
+        assert int(gold["counters"][7]) == 0, "reference paths A and B disagree"
+        np.savez_compressed(os.path.join(d, "%s.%s.npz" % (name, pname)), params=np.array(PARAM_SETS[pname], dtype="U16"), **gold)
+        manifest["runs"]["%s.%s" % (name, pname)] = r.stderr.strip().splitlines()[-1]
+        if i == 0:
+            np.savez_compressed(os.path.join(d, "prims.npz"), **parse_prims(ptmp))
+            os.remove(ptmp)
+    os.remove(tmp)
+    for fn in sorted(os.listdir(d)):
+        manifest["md5"]["g1/" + fn] = md5(os.path.join(d, fn))
+    json.dump(manifest, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(manifest["runs"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
