@@ -1,0 +1,61 @@
+"""Shared helpers for the tests: golden fixtures, read files, synthetic inputs."""
+import glob
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "g1")
+PREFIX = os.path.join(GOLD, "ref")
+
+PARAM_FLAGS = {"-k": "k", "-r": "r", "-y": "y", "-c": "c", "-s": "s"}
+
+
+def golden_runs():
+    """[(reads_name, params_name)] for every committed golden run."""
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLD, "*.npz"))):
+        b = os.path.basename(p)[:-4]
+        if b == "prims":
+            continue
+        name, pname = b.split(".", 1)
+        out.append((name, pname))
+    return out
+
+
+def load_golden(name, pname):
+    z = np.load(os.path.join(GOLD, "%s.%s.npz" % (name, pname)))
+    flags = [str(x) for x in z["params"]]
+    kw = {}
+    for i in range(0, len(flags), 2):
+        key = PARAM_FLAGS[flags[i]]
+        kw[key] = float(flags[i + 1]) if key == "r" else int(flags[i + 1])
+    return z, kw
+
+
+def load_reads(name):
+    """one read per line (CompSeed reordered-reads format, main.cpp:36-58) -> (bases uint8[], offsets uint64[n+1])"""
+    raw = open(os.path.join(GOLD, name + ".txt"), "rb").read()
+    return pack_reads(raw.split(b"\n")[:-1] if raw.endswith(b"\n") else raw.split(b"\n"))
+
+
+def pack_reads(reads):
+    lens = np.array([len(r) for r in reads], dtype=np.uint64)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    return bases, off
+
+
+def load_bwt_files(prefix=PREFIX):
+    """Parse <prefix>.bwt / .sa (formats FM_index/bwt.c:385-462) into numpy arrays."""
+    b = np.fromfile(prefix + ".bwt", dtype=np.uint8)
+    primary = int(b[:8].view("<u8")[0])
+    L2 = b[8:40].view("<u8").copy()
+    words = b[40:].view("<u4").copy()
+    s = np.fromfile(prefix + ".sa", dtype="<u8")
+    assert int(s[0]) == primary and int(s[6]) == int(L2[3])
+    sa_intv = int(s[5])
+    sa = s[6:].copy()
+    sa[0] = np.uint64(2**64 - 1)
+    return dict(primary=primary, L2=L2, bwt=words, sa=sa, sa_intv=sa_intv, seq_len=int(L2[3]))

@@ -1,0 +1,140 @@
+"""ctypes binding of oracle/libcsoracle.so -- the CPU restatement used as the CHECKER by the tests.
+
+Test infrastructure only: nothing under compseed_amd/ imports this module or the library behind it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libcsoracle.so")
+
+INTV_DT = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")])
+SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+
+
+class Intv(C.Structure):
+    _fields_ = [("x0", C.c_uint64), ("x1", C.c_uint64), ("x2", C.c_uint64), ("info", C.c_uint64)]
+
+
+class Index(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.c_void_p), ("sa_intv", C.c_uint64), ("n_sa", C.c_uint64), ("sa", C.c_void_p),
+                ("owned_bwt", C.c_void_p), ("owned_sa", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_seed_len", C.c_int32), ("split_factor", C.c_float), ("split_width", C.c_int32),
+                ("max_occ", C.c_int32), ("max_mem_intv", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("bwt_queries", "bwt_calls", "bwt_blocks", "bwt_blocks_uncached", "sal_queries",
+                                          "sal_calls", "sal_steps", "sal_steps_uncached", "n_mems", "n_seeds")]
+
+    def asdict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src_newer = (not os.path.exists(LIB_PATH) or
+                     any(os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
+                         for f in ("cs_oracle.c", "cs_oracle.h")))
+        if src_newer:
+            subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, capture_output=True)
+        L = C.CDLL(LIB_PATH)
+        L.cso_index_load.argtypes = [C.POINTER(Index), C.c_char_p]
+        L.cso_index_wrap.argtypes = [C.POINTER(Index), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.cso_index_free.argtypes = [C.POINTER(Index)]
+        L.cso_occ4.argtypes = [C.POINTER(Index), C.c_uint64, C.POINTER(C.c_uint64)]
+        L.cso_2occ4.argtypes = [C.POINTER(Index), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.cso_extend.argtypes = [C.POINTER(Index), C.POINTER(Intv), C.POINTER(Intv), C.c_int]
+        L.cso_sa.argtypes = [C.POINTER(Index), C.c_uint64, C.POINTER(C.c_uint64)]
+        L.cso_sa.restype = C.c_uint64
+        L.cso_params_default.argtypes = [C.POINTER(Params)]
+        L.cso_seed_batch.argtypes = [C.POINTER(Index), C.POINTER(Params), C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), C.POINTER(Stats)]
+        L.cso_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def make_params(k=19, r=1.5, s=10, c=500, y=20):
+    p = Params()
+    p.min_seed_len, p.split_factor, p.split_width, p.max_occ, p.max_mem_intv = k, r, s, c, y
+    return p
+
+
+class OracleIndex:
+    """Index handle: from files (`prefix`) or from arrays (`from_arrays`)."""
+
+    def __init__(self, prefix=None):
+        self.idx = Index()
+        self._keep = []
+        if prefix is not None:
+            rc = lib().cso_index_load(C.byref(self.idx), prefix.encode())
+            if rc:
+                raise IOError("cso_index_load(%s) failed: %d" % (prefix, rc))
+
+    @classmethod
+    def from_arrays(cls, primary, L2_1to4, bwt_words, sa, sa_intv=32):
+        self = cls()
+        l2 = np.ascontiguousarray(L2_1to4, dtype=np.uint64)
+        bwt = np.ascontiguousarray(bwt_words, dtype=np.uint32)
+        sa = np.ascontiguousarray(sa, dtype=np.uint64)
+        self._keep = [l2, bwt, sa]
+        lib().cso_index_wrap(C.byref(self.idx), int(primary), l2.ctypes.data, bwt.ctypes.data, bwt.size, sa.ctypes.data, sa.size, sa_intv)
+        return self
+
+    def close(self):
+        lib().cso_index_free(C.byref(self.idx))
+
+    def occ4(self, k):
+        out = (C.c_uint64 * 4)()
+        lib().cso_occ4(C.byref(self.idx), C.c_uint64(int(k) & (2**64 - 1)), out)
+        return list(out)
+
+    def occ2x4(self, k, l):
+        a = (C.c_uint64 * 4)(); b = (C.c_uint64 * 4)()
+        nb = lib().cso_2occ4(C.byref(self.idx), C.c_uint64(int(k) & (2**64 - 1)), C.c_uint64(int(l) & (2**64 - 1)), a, b)
+        return list(a), list(b), nb
+
+    def extend(self, x0, x1, x2, is_back):
+        ik = Intv(int(x0), int(x1), int(x2), 0)
+        ok = (Intv * 4)()
+        lib().cso_extend(C.byref(self.idx), C.byref(ik), ok, int(is_back))
+        return [(o.x0, o.x1, o.x2) for o in ok]
+
+    def sa(self, k):
+        return int(lib().cso_sa(C.byref(self.idx), int(k), None))
+
+    def seed_batch(self, bases, offsets, params=None, mode=0, sst_batch=512, want_sal=True, threads=1):
+        """bases: uint8 array (ASCII or nt4), offsets: uint64[n+1].  Returns dict of numpy arrays + stats."""
+        params = params or make_params()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        mo, mm, so, ss = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        st = Stats()
+        rc = lib().cso_seed_batch(C.byref(self.idx), C.byref(params), n, bases.ctypes.data, offsets.ctypes.data, mode, sst_batch,
+                                  int(want_sal), threads, C.byref(mo), C.byref(mm), C.byref(so), C.byref(ss), C.byref(st))
+        assert rc == 0
+        def take(ptr, dt, cnt):
+            if cnt == 0:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (cnt * np.dtype(dt).itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dt, count=cnt).copy()
+        out = dict(mem_off=take(mo, "<u8", n + 1), mems=take(mm, INTV_DT, int(st.n_mems)),
+                   seed_off=take(so, "<u8", n + 1), seeds=take(ss, SEED_DT, int(st.n_seeds)), stats=st.asdict())
+        for p in (mo, mm, so, ss):
+            lib().cso_free(p)
+        return out
