@@ -1,0 +1,12 @@
+"""compseed_amd -- MI355X-native compressive SMEM seeding (host-side Python mirror of include/compseed_amd.h).
+
+The product is the HIP library `libcompseed_amd.so` behind a plain C ABI; this package only binds it with ctypes
+so that tests, bench.py and Python callers can drive the same entry points a C/C++ host (CompSeed's
+seed_and_extend) would.  There is no CPU fallback: importing works anywhere, but creating an
+Engine without the built library or without a GPU raises.
+"""
+from .binding import (CSError, Engine, Index, Params, Result, Stats, lib_path, load_library, build_library,  # noqa: F401
+                      INTV_DT, SEED_DT)
+
+__all__ = ["CSError", "Engine", "Index", "Params", "Result", "Stats", "lib_path", "load_library", "build_library",
+           "INTV_DT", "SEED_DT"]

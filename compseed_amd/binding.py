@@ -1,0 +1,273 @@
+"""ctypes binding of libcompseed_amd.so (C ABI: include/compseed_amd.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+INTV_DT = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")])   # cs_intv_t == bwtintv_t
+SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])               # cs_seed_t
+
+# every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
+SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free",
+           "cs_device_count", "cs_engine_create", "cs_engine_destroy", "cs_engine_seed_batch",
+           "cs_engine_seed_batch_device", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
+           "cs_engine_extend", "cs_engine_sa", "cs_device_alloc", "cs_device_free", "cs_device_upload",
+           "cs_device_download", "cs_device_sync"]
+
+
+class CSError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("compseed_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IndexView(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.c_void_p), ("sa_intv", C.c_uint64), ("n_sa", C.c_uint64), ("sa", C.c_void_p)]
+
+
+class Params(C.Structure):
+    """cs_params_t; defaults = mem_opt_init (mapping/comp_seed.cpp:26-58)."""
+    _fields_ = [("min_seed_len", C.c_int32), ("split_factor", C.c_float), ("split_width", C.c_int32),
+                ("max_occ", C.c_int32), ("max_mem_intv", C.c_uint64), ("want_sal", C.c_int32), ("sst_mode", C.c_int32)]
+
+    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=0):
+        super().__init__(k, r, s, c, y, want_sal, sst_mode)
+
+
+class CResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_mems", C.c_uint64), ("n_seeds", C.c_uint64), ("mem_off", C.c_void_p),
+                ("mems", C.c_void_p), ("seed_off", C.c_void_p), ("seeds", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("bases", C.c_uint64), ("mems", C.c_uint64), ("seeds", C.c_uint64),
+                ("bwt_queries", C.c_uint64), ("bwt_calls", C.c_uint64), ("sal_queries", C.c_uint64),
+                ("sal_calls", C.c_uint64), ("overflow_reads", C.c_uint64), ("seed_kernel_ms", C.c_double),
+                ("sal_kernel_ms", C.c_double), ("total_ms", C.c_double), ("seed_kernel_launches", C.c_uint64)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libcompseed_amd.so")
+
+
+def build_library(force=False):
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950; works without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", src, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", src, "all"], capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("building libcompseed_amd.so failed:\n" + r.stdout + r.stderr)
+    return lib_path()
+
+
+_lib = None
+
+
+def load_library():
+    """Load the C-ABI library; fails loudly when it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C compseed_amd/csrc`" % p)
+    L = C.CDLL(p)
+    vp, i64, u64p = C.c_void_p, C.c_int64, C.c_void_p
+    L.cs_last_error.restype = C.c_char_p
+    L.cs_version.restype = C.c_char_p
+    L.cs_params_default.argtypes = [C.POINTER(Params)]
+    L.cs_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.cs_index_view.argtypes = [vp, C.POINTER(IndexView)]
+    L.cs_index_free.argtypes = [vp]
+    L.cs_index_free.restype = None
+    L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
+    L.cs_engine_destroy.argtypes = [vp]
+    L.cs_engine_destroy.restype = None
+    L.cs_engine_seed_batch.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.POINTER(CResult)]
+    L.cs_engine_seed_batch_device.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.c_uint64, C.POINTER(CResult)]
+    L.cs_engine_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.cs_engine_reset_stats.argtypes = [vp]
+    L.cs_engine_reset_stats.restype = None
+    L.cs_engine_occ4.argtypes = [vp, i64, vp, vp]
+    L.cs_engine_extend.argtypes = [vp, i64, vp, vp, vp]
+    L.cs_engine_sa.argtypes = [vp, i64, vp, vp]
+    L.cs_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.cs_device_free.argtypes = [vp, vp]
+    L.cs_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.cs_device_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.cs_device_sync.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise CSError(rc, load_library().cs_last_error().decode(errors="replace"))
+
+
+class Index:
+    """Host copy of an FM-index: from the reference's files (<prefix>.bwt/.sa) or from numpy arrays."""
+
+    def __init__(self):
+        self.view = IndexView()
+        self._handle = None
+        self._keep = []
+
+    @classmethod
+    def load(cls, prefix):
+        self = cls()
+        L = load_library()
+        h = C.c_void_p()
+        _check(L.cs_index_load(os.fsencode(prefix), C.byref(h)))
+        self._handle = h
+        _check(L.cs_index_view(h, C.byref(self.view)))
+        return self
+
+    @classmethod
+    def from_arrays(cls, primary, L2_1to4, bwt_words, sa, sa_intv=32):
+        self = cls()
+        bwt = np.ascontiguousarray(bwt_words, dtype=np.uint32)
+        sa = np.ascontiguousarray(sa, dtype=np.uint64)
+        self._keep = [bwt, sa]
+        v = self.view
+        v.primary = int(primary)
+        v.L2[0] = 0
+        for i in range(4):
+            v.L2[i + 1] = int(L2_1to4[i])
+        v.seq_len = int(L2_1to4[3])
+        v.bwt_size = bwt.size
+        v.bwt = bwt.ctypes.data
+        v.sa_intv = sa_intv
+        v.n_sa = sa.size
+        v.sa = sa.ctypes.data
+        return self
+
+    def close(self):
+        if self._handle is not None:
+            load_library().cs_index_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Result:
+    """CSR result of one batch as numpy arrays (host variant) or raw device pointers (device variant)."""
+
+    def __init__(self, cres, on_device, want_sal):
+        self.n_reads, self.n_mems, self.n_seeds = int(cres.n_reads), int(cres.n_mems), int(cres.n_seeds)
+        self.on_device = on_device
+        self.ptr = dict(mem_off=cres.mem_off, mems=cres.mems, seed_off=cres.seed_off, seeds=cres.seeds)
+        if not on_device:
+            self.mem_off = _view(cres.mem_off, "<u8", self.n_reads + 1)
+            self.mems = _view(cres.mems, INTV_DT, self.n_mems)
+            self.seed_off = _view(cres.seed_off, "<u8", self.n_reads + 1) if want_sal else None
+            self.seeds = _view(cres.seeds, SEED_DT, self.n_seeds) if want_sal else None
+
+
+def _view(ptr, dt, n):
+    dt = np.dtype(dt)
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dt)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+
+class Engine:
+    """One GPU, one resident index (cs_engine_t)."""
+
+    def __init__(self, index, device=0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        self._index = index  # keep host arrays alive during upload
+        _check(self._L.cs_engine_create(C.byref(index.view), int(device), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._L.cs_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot path
+    def seed_batch(self, bases, offsets, params=None):
+        """Host buffers in, numpy CSR out (cs_engine_seed_batch)."""
+        params = params or Params()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = CResult()
+        _check(self._L.cs_engine_seed_batch(self._h, C.byref(params), offsets.size - 1, bases.ctypes.data, offsets.ctypes.data, C.byref(res)))
+        return Result(res, False, bool(params.want_sal))
+
+    def seed_batch_device(self, d_bases, d_offsets, n_reads, n_bases, params=None):
+        """Device pointers (ints) in, device pointers out (cs_engine_seed_batch_device): no PCIe traffic in the call."""
+        params = params or Params()
+        res = CResult()
+        _check(self._L.cs_engine_seed_batch_device(self._h, C.byref(params), int(n_reads), C.c_void_p(d_bases), C.c_void_p(d_offsets),
+                                                   int(n_bases), C.byref(res)))
+        return Result(res, True, bool(params.want_sal))
+
+    def stats(self):
+        st = Stats()
+        _check(self._L.cs_engine_stats(self._h, C.byref(st)))
+        return st.asdict()
+
+    def reset_stats(self):
+        self._L.cs_engine_reset_stats(self._h)
+
+    # ---- primitives (parity tests of the building blocks)
+    def occ4(self, k):
+        k = np.ascontiguousarray(k, dtype=np.uint64)
+        out = np.zeros((k.size, 4), dtype=np.uint64)
+        _check(self._L.cs_engine_occ4(self._h, k.size, k.ctypes.data, out.ctypes.data))
+        return out
+
+    def extend(self, ik, is_back):
+        ik = np.ascontiguousarray(ik, dtype=INTV_DT)
+        fb = np.ascontiguousarray(is_back, dtype=np.uint8)
+        out = np.zeros((ik.size, 4), dtype=INTV_DT)
+        _check(self._L.cs_engine_extend(self._h, ik.size, ik.ctypes.data, fb.ctypes.data, out.ctypes.data))
+        return out
+
+    def sa(self, k):
+        k = np.ascontiguousarray(k, dtype=np.uint64)
+        out = np.zeros(k.size, dtype=np.uint64)
+        _check(self._L.cs_engine_sa(self._h, k.size, k.ctypes.data, out.ctypes.data))
+        return out
+
+    # ---- device memory helpers
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(self._L.cs_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        _check(self._L.cs_device_free(self._h, C.c_void_p(dptr)))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(self._L.cs_device_upload(self._h, C.c_void_p(dptr), arr.ctypes.data, arr.nbytes))
+
+    def download(self, dptr, dtype, count):
+        out = np.zeros(count, dtype=dtype)
+        _check(self._L.cs_device_download(self._h, out.ctypes.data, C.c_void_p(dptr), out.nbytes))
+        return out
+
+    def sync(self):
+        _check(self._L.cs_device_sync(self._h))

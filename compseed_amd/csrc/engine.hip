@@ -1,0 +1,624 @@
+// engine.hip -- C-ABI implementation (include/compseed_amd.h): device residency of the index, batch orchestration.
+//
+// Host-side counterpart of mem_process_seqs -> seed_and_extend (mapping/comp_seed.cpp:2527, 2242) for the seeding
+// and SAL blocks only.  No CPU fallback exists: without a HIP device every entry point fails with CS_EDEVICE.
+#include "../../include/compseed_amd.h"
+#include "seed_kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+using namespace csd;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e__ = (expr);                                                                   \
+		if (e__ != hipSuccess) {                                                                   \
+			(void)hipGetLastError();                                                               \
+			return fail(e__ == hipErrorOutOfMemory ? CS_ENOMEM : CS_EDEVICE,                       \
+			            std::string(#expr) + ": " + hipGetErrorString(e__));                       \
+		}                                                                                          \
+	} while (0)
+#define CS_TRY(expr) do { int rc__ = (expr); if (rc__ != CS_OK) return rc__; } while (0)
+
+extern "C" const char *cs_last_error(void) { return g_err.c_str(); }
+extern "C" const char *cs_version(void) { return "compseed_amd 0.1 (gfx950)"; }
+
+extern "C" void cs_params_default(cs_params_t *p)
+{
+	if (!p) return;
+	p->min_seed_len = 19; p->split_factor = 1.5f; p->split_width = 10; p->max_occ = 500; p->max_mem_intv = 20;
+	p->want_sal = 1; p->sst_mode = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ grow-only buffers
+template <typename T> struct DevBuf {
+	T *p = nullptr; size_t cap = 0;
+	int reserve(size_t n, bool keep = false, hipStream_t s = nullptr, size_t keep_n = 0)
+	{
+		if (n <= cap) return CS_OK;
+		size_t want = std::max(n, cap + cap / 2);
+		T *q = nullptr;
+		HIP_TRY(hipMalloc((void **)&q, want * sizeof(T)));
+		if (keep && p && keep_n) {
+			hipError_t e = hipMemcpyAsync(q, p, keep_n * sizeof(T), hipMemcpyDeviceToDevice, s);
+			if (e == hipSuccess) e = hipStreamSynchronize(s);
+			if (e != hipSuccess) { (void)hipFree(q); return fail(CS_EDEVICE, hipGetErrorString(e)); }
+		}
+		if (p) (void)hipFree(p);
+		p = q; cap = want;
+		return CS_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+	T *p = nullptr; size_t cap = 0;
+	int reserve(size_t n)
+	{
+		if (n <= cap) return CS_OK;
+		size_t want = std::max(n, cap + cap / 2);
+		if (p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+		cap = want;
+		return CS_OK;
+	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct cs_index {
+	cs_index_view_t v;
+	std::vector<uint32_t> bwt;
+	std::vector<uint64_t> sa;
+};
+
+struct cs_engine {
+	int device = 0;
+	int n_cu = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	DevIndex ix{};
+	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
+	// inputs
+	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
+	// SMEM stage
+	DevBuf<OutMem> d_out, d_out2; DevBuf<uint32_t> d_cnt, d_cnt2, d_ovf; DevBuf<uint4> d_spill;
+	DevBuf<unsigned long long> d_ctr; // [0] task counter, [1] queries, [2] overflow count, [3] max len
+	DevBuf<uint8_t> d_tmp, d_tmp2;
+	// results (device)
+	DevBuf<uint64_t> d_mem_off, d_seed_off, d_seed_of_mem; DevBuf<OutMem> d_mems; DevBuf<OutSeed> d_seeds;
+	// results (pinned host)
+	PinBuf<uint64_t> h_mem_off, h_seed_off; PinBuf<OutMem> h_mems; PinBuf<OutSeed> h_seeds;
+	PinBuf<unsigned long long> h_ctr;
+	cs_stats_t st{};
+	uint32_t cap = 32;          // mems per read kept by the first pass
+	size_t max_raw_bytes = (size_t)24 << 30;
+	int blocks_per_cu = 2;
+};
+
+// ------------------------------------------------------------------------------------------------ index files
+static bool read_file(const std::string &fn, std::vector<uint8_t> &buf)
+{
+	FILE *fp = fopen(fn.c_str(), "rb");
+	if (!fp) return false;
+	fseek(fp, 0, SEEK_END);
+	long sz = ftell(fp);
+	fseek(fp, 0, SEEK_SET);
+	buf.resize((size_t)sz);
+	size_t got = sz ? fread(buf.data(), 1, (size_t)sz, fp) : 0;
+	fclose(fp);
+	return got == (size_t)sz;
+}
+
+extern "C" int cs_index_load(const char *prefix, cs_index_t **out)
+{
+	if (!prefix || !out) return fail(CS_EINVAL, "cs_index_load: null argument");
+	*out = nullptr;
+	std::string pre(prefix);
+	{ // bwa_idx_infer_prefix (bwalib/bwa.c:244-268): accept "<hint>.64" if it exists
+		FILE *fp = fopen((pre + ".64.bwt").c_str(), "rb");
+		if (fp) { fclose(fp); pre += ".64"; }
+	}
+	std::vector<uint8_t> raw;
+	if (!read_file(pre + ".bwt", raw) || raw.size() < 40 + 64) return fail(CS_EIO, "cannot read " + pre + ".bwt");
+	cs_index *ix = new cs_index();
+	cs_index_view_t &v = ix->v;
+	memset(&v, 0, sizeof v);
+	memcpy(&v.primary, raw.data(), 8);           // bwt_restore_bwt, bwt.c:443-462
+	memcpy(&v.L2[1], raw.data() + 8, 32);
+	v.L2[0] = 0; v.seq_len = v.L2[4];
+	v.bwt_size = (raw.size() - 40) >> 2;
+	ix->bwt.resize(v.bwt_size);
+	memcpy(ix->bwt.data(), raw.data() + 40, v.bwt_size * 4);
+	if (!read_file(pre + ".sa", raw) || raw.size() < 56) { delete ix; return fail(CS_EIO, "cannot read " + pre + ".sa"); }
+	uint64_t h[7];
+	memcpy(h, raw.data(), 56);                   // bwt_restore_sa, bwt.c:421-441
+	if (h[0] != v.primary) { delete ix; return fail(CS_EIO, "SA-BWT inconsistency: primary is not the same"); }
+	if (h[6] != v.seq_len) { delete ix; return fail(CS_EIO, "SA-BWT inconsistency: seq_len is not the same"); }
+	v.sa_intv = h[5];
+	if (v.sa_intv == 0 || (v.sa_intv & (v.sa_intv - 1))) { delete ix; return fail(CS_EIO, "SA sample interval is not a power of 2"); }
+	v.n_sa = (v.seq_len + v.sa_intv) / v.sa_intv;
+	if ((raw.size() - 56) / 8 < v.n_sa - 1) { delete ix; return fail(CS_EIO, pre + ".sa is truncated"); }
+	ix->sa.resize(v.n_sa);
+	ix->sa[0] = ~0ull;
+	memcpy(ix->sa.data() + 1, raw.data() + 56, (v.n_sa - 1) * 8);
+	v.bwt = ix->bwt.data(); v.sa = ix->sa.data();
+	*out = ix;
+	return CS_OK;
+}
+extern "C" int cs_index_view(const cs_index_t *idx, cs_index_view_t *view)
+{
+	if (!idx || !view) return fail(CS_EINVAL, "cs_index_view: null argument");
+	*view = idx->v;
+	return CS_OK;
+}
+extern "C" void cs_index_free(cs_index_t *idx) { delete idx; }
+
+// ------------------------------------------------------------------------------------------------ engine
+extern "C" int cs_device_count(int *n)
+{
+	if (!n) return fail(CS_EINVAL, "null argument");
+	*n = 0;
+	HIP_TRY(hipGetDeviceCount(n));
+	return CS_OK;
+}
+
+static int engine_init(cs_engine *e, const cs_index_view_t *v)
+{
+	int ndev = 0;
+	HIP_TRY(hipGetDeviceCount(&ndev));
+	if (ndev <= 0) return fail(CS_EDEVICE, "no HIP device: the seeding engine has no CPU path");
+	if (e->device < 0 || e->device >= ndev) return fail(CS_EINVAL, "device ordinal out of range");
+	HIP_TRY(hipSetDevice(e->device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+	e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+	for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+
+	if (v->seq_len == 0 || v->seq_len != v->L2[4] || v->L2[0] != 0) return fail(CS_EINVAL, "index view: L2 / seq_len inconsistent");
+	if (v->seq_len >> 37) return fail(CS_ERANGE, "index longer than 2^37 symbols does not fit the packed LEP entries");
+	if (v->primary > v->seq_len) return fail(CS_EINVAL, "index view: primary out of range");
+	uint64_t n_blocks = (v->seq_len + 127) >> 7;
+	// the file holds one extra count record after the last block (bwt_bwtupdate_core, index_main.c:152-174)
+	if (v->bwt_size < n_blocks * 16) return fail(CS_EINVAL, "index view: bwt array shorter than seq_len requires");
+	if (v->sa_intv == 0 || (v->sa_intv & (v->sa_intv - 1))) return fail(CS_EINVAL, "index view: sa_intv is not a power of two");
+	if (v->n_sa != (v->seq_len + v->sa_intv) / v->sa_intv) return fail(CS_EINVAL, "index view: n_sa inconsistent");
+
+	size_t quads = (size_t)((v->bwt_size + 3) >> 2) + 8; // pad: a block load never leaves the allocation
+	CS_TRY(e->d_bwt.reserve(quads));
+	HIP_TRY(hipMemsetAsync(e->d_bwt.p, 0, quads * sizeof(uint4), e->stream));
+	HIP_TRY(hipMemcpyAsync(e->d_bwt.p, v->bwt, (size_t)v->bwt_size * 4, hipMemcpyHostToDevice, e->stream));
+	CS_TRY(e->d_sa.reserve((size_t)v->n_sa));
+	HIP_TRY(hipMemcpyAsync(e->d_sa.p, v->sa, (size_t)v->n_sa * 8, hipMemcpyHostToDevice, e->stream));
+	CS_TRY(e->d_ctr.reserve(8));
+	CS_TRY(e->h_ctr.reserve(8));
+	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 8 * sizeof(unsigned long long), e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+
+	DevIndex &ix = e->ix;
+	ix.bwt = e->d_bwt.p; ix.sa = e->d_sa.p;
+	ix.primary = v->primary; ix.seq_len = v->seq_len; ix.n_sa = v->n_sa; ix.n_blocks = n_blocks;
+	for (int i = 0; i < 5; ++i) ix.L2[i] = v->L2[i];
+	ix.sa_mask = (uint32_t)(v->sa_intv - 1);
+	ix.sa_shift = (uint32_t)__builtin_ctzll(v->sa_intv);
+
+	if (const char *s = getenv("CS_MEM_CAP")) { int c = atoi(s); if (c >= 1 && c <= 4096) e->cap = (uint32_t)c; }
+	if (const char *s = getenv("CS_MAX_RAW_MB")) { long m = atol(s); if (m >= 1) e->max_raw_bytes = (size_t)m << 20; }
+	return CS_OK;
+}
+
+extern "C" int cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out)
+{
+	if (!index || !out || !index->bwt || !index->sa) return fail(CS_EINVAL, "cs_engine_create: null argument");
+	*out = nullptr;
+	cs_engine *e = new cs_engine();
+	e->device = device;
+	int rc = engine_init(e, index);
+	if (rc != CS_OK) { std::string keep = g_err; cs_engine_destroy(e); g_err = keep; return rc; }
+	*out = e;
+	return CS_OK;
+}
+
+extern "C" void cs_engine_destroy(cs_engine_t *e)
+{
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	e->d_bwt.release(); e->d_sa.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
+	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
+	e->d_mems.release(); e->d_seeds.release();
+	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
+	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+	if (e->stream) (void)hipStreamDestroy(e->stream);
+	delete e;
+}
+
+extern "C" int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st)
+{
+	if (!e || !st) return fail(CS_EINVAL, "null argument");
+	*st = e->st;
+	return CS_OK;
+}
+extern "C" void cs_engine_reset_stats(cs_engine_t *e) { if (e) memset(&e->st, 0, sizeof e->st); }
+
+// ------------------------------------------------------------------------------------------------ helpers
+struct U32ToU64 { __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
+
+// exclusive prefix sum of n u32 counts into n+1 u64 offsets starting at `init`
+static int scan_counts(cs_engine *e, const uint32_t *cnt, uint64_t *off, size_t n, uint64_t init)
+{
+	auto in = rocprim::make_transform_iterator(cnt, U32ToU64());
+	size_t tmp = 0;
+	// n+1 outputs: the input iterator is read one past the end, so cnt has a zeroed tail slot
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, in, off, init, n + 1, rocprim::plus<uint64_t>(), e->stream));
+	CS_TRY(e->d_tmp.reserve(tmp + 16));
+	HIP_TRY(rocprim::exclusive_scan(e->d_tmp.p, tmp, in, off, init, n + 1, rocprim::plus<uint64_t>(), e->stream));
+	return CS_OK;
+}
+static int scan_u64(cs_engine *e, const uint64_t *cnt, uint64_t *off, size_t n)
+{
+	size_t tmp = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, cnt, off, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), e->stream));
+	CS_TRY(e->d_tmp.reserve(tmp + 16));
+	HIP_TRY(rocprim::exclusive_scan(e->d_tmp.p, tmp, cnt, off, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), e->stream));
+	return CS_OK;
+}
+
+__global__ void max_len_kernel(const uint64_t *off, int64_t n, unsigned long long *out_max, unsigned long long *bad)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	uint64_t a = off[r], b = off[r + 1];
+	if (b < a) { atomicAdd(bad, 1ull); return; }
+	atomicMax(out_max, (unsigned long long)(b - a));
+}
+__global__ void collect_overflow_kernel(const uint32_t *cnt, int64_t n, uint32_t cap, uint32_t first_read, uint32_t *list, unsigned long long *n_ovf)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n || cnt[r] <= cap) return;
+	unsigned long long slot = atomicAdd(n_ovf, 1ull);
+	list[slot] = first_read + (uint32_t)r;
+}
+__global__ void patch_counts_kernel(const uint32_t *cnt2, const uint32_t *list, int64_t n_ovf, uint32_t first_read, uint32_t *cnt)
+{
+	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_ovf) return;
+	cnt[list[t] - first_read] = cnt2[t];
+}
+// second-pass variant of sort_compact_kernel: task t holds read list[t]
+__global__ void sort_compact_list_kernel(const OutMem *raw, const uint32_t *cnt2, uint32_t cap2, const uint32_t *list, int64_t n_tasks,
+                                         const uint64_t *mem_off, OutMem *mems)
+{
+	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_tasks) return;
+	uint32_t n = cnt2[t];
+	const OutMem *src = raw + (size_t)t * cap2;
+	OutMem *dst = mems + mem_off[list[t]];
+	for (uint32_t a = 0; a < n; ++a) {
+		uint64_t ka = src[a].info; uint32_t rank = 0;
+		for (uint32_t b = 0; b < n; ++b) { uint64_t kb = src[b].info; rank += (kb < ka) || (kb == ka && b < a); }
+		dst[rank] = src[a];
+	}
+}
+
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)std::max<int64_t>(1, (n + block - 1) / block); }
+
+constexpr int SMEM_BLOCK = 256;
+constexpr int SMEM_LEP_LDS = 20; // 20 x 16 B x 256 lanes = 80 KiB of LDS per workgroup, two workgroups per CU
+
+static int launch_smem(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, const uint32_t *d_ids, int64_t n_tasks,
+                       OutMem *out, uint32_t *cnt, uint32_t cap, uint32_t max_len)
+{
+	unsigned blocks = (unsigned)std::min<int64_t>((int64_t)e->n_cu * e->blocks_per_cu, (n_tasks + SMEM_BLOCK - 1) / SMEM_BLOCK);
+	if (blocks == 0) return CS_OK;
+	uint32_t spill_cap = max_len + 1 > (uint32_t)SMEM_LEP_LDS ? max_len + 1 - SMEM_LEP_LDS : 1;
+	// long reads: fewer resident workgroups rather than an unbounded spill area (one LEP list per lane, worst case = read length)
+	size_t per_block = (size_t)SMEM_BLOCK * spill_cap * sizeof(uint4);
+	blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, ((size_t)8 << 30) / per_block));
+	CS_TRY(e->d_spill.reserve((size_t)blocks * SMEM_BLOCK * spill_cap));
+	SeedArgs A;
+	A.ix = e->ix; A.seq = e->d_seq.p; A.off = d_off; A.read_ids = d_ids; A.n_tasks = n_tasks;
+	A.out = out; A.out_cnt = cnt; A.cap = cap;
+	A.min_seed_len = par->min_seed_len;
+	A.split_len = (int)(1.0 * par->min_seed_len * par->split_factor + .499); // comp_seed.cpp:2279 (double arithmetic)
+	A.split_width = (uint32_t)par->split_width;
+	A.max_mem_intv = par->max_mem_intv;
+	A.task_counter = e->d_ctr.p; A.spill = e->d_spill.p; A.spill_cap = spill_cap; A.n_queries = e->d_ctr.p + 1;
+	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, sizeof(unsigned long long), e->stream));
+	HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+	hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, SMEM_LEP_LDS>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+	e->st.seed_kernel_launches++;
+	return CS_OK;
+}
+
+static int add_event_ms(cs_engine *e, hipEvent_t a, hipEvent_t b, double *acc)
+{
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, a, b));
+	*acc += ms;
+	return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the hot path
+static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
+                            uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out)
+{
+	hipStream_t s = e->stream;
+	*n_mems_out = *n_seeds_out = 0;
+	if (par->min_seed_len < 1 || par->max_occ < 1 || par->split_width < 0) return fail(CS_EINVAL, "bad seeding parameters");
+	CS_TRY(e->d_mem_off.reserve((size_t)n_reads + 2));
+	if (n_reads == 0) {
+		HIP_TRY(hipMemsetAsync(e->d_mem_off.p, 0, 8, s));
+		if (par->want_sal) { CS_TRY(e->d_seed_off.reserve(2)); HIP_TRY(hipMemsetAsync(e->d_seed_off.p, 0, 8, s)); }
+		HIP_TRY(hipStreamSynchronize(s));
+		return CS_OK;
+	}
+	HIP_TRY(hipEventRecord(e->ev[2], s));
+	// read lengths: MAX_READ_LEN 65535 (comp_seed.h:39; the reference aborts at main.cpp:83-86)
+	HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, 3 * sizeof(unsigned long long), s));
+	hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, s, d_off, n_reads, e->d_ctr.p + 3, e->d_ctr.p + 4);
+	HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (e->h_ctr.p[4]) return fail(CS_EINVAL, "offsets are not non-decreasing");
+	uint32_t max_len = (uint32_t)e->h_ctr.p[3];
+	if (e->h_ctr.p[3] >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
+
+	// ASCII -> nt4 into a private padded buffer (the caller's reads stay untouched)
+	CS_TRY(e->d_seq.reserve((size_t)n_bases + 64));
+	if (n_bases) {
+		unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256, (uint64_t)e->n_cu * 16);
+		hipLaunchKernelGGL(nt4_kernel, dim3(g), dim3(256), 0, s, d_bases, e->d_seq.p, n_bases);
+	}
+	HIP_TRY(hipMemsetAsync(e->d_seq.p + n_bases, 4, 64, s));
+
+	const uint32_t cap = e->cap;
+	int64_t per_launch = (int64_t)std::max<size_t>(1024, e->max_raw_bytes / ((size_t)cap * sizeof(OutMem)));
+	per_launch = std::min<int64_t>(per_launch, n_reads);
+	CS_TRY(e->d_out.reserve((size_t)per_launch * cap));
+	CS_TRY(e->d_cnt.reserve((size_t)per_launch + 1));
+	CS_TRY(e->d_ovf.reserve((size_t)per_launch));
+	CS_TRY(e->d_mems.reserve((size_t)n_reads * 10 + 1024));
+
+	uint64_t total_mems = 0;
+	for (int64_t b0 = 0; b0 < n_reads; b0 += per_launch) {
+		int64_t nb = std::min<int64_t>(per_launch, n_reads - b0);
+		HIP_TRY(hipMemsetAsync(e->d_cnt.p + nb, 0, sizeof(uint32_t), s));
+		CS_TRY(launch_smem(e, par, d_off + b0, nullptr, nb, e->d_out.p, e->d_cnt.p, cap, max_len));
+		HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, sizeof(unsigned long long), s));
+		hipLaunchKernelGGL(collect_overflow_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, e->d_cnt.p, nb, cap, 0u, e->d_ovf.p, e->d_ctr.p + 2);
+		HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
+		e->st.bwt_queries += e->h_ctr.p[1]; e->st.bwt_calls += e->h_ctr.p[1];
+		HIP_TRY(hipMemsetAsync(e->d_ctr.p + 1, 0, sizeof(unsigned long long), s));
+		int64_t n_ovf = (int64_t)e->h_ctr.p[2];
+		uint32_t cap2 = 0;
+		if (n_ovf > 0) { // second pass over the few reads with more than `cap` mems, capacity grown until everything fits
+			e->st.overflow_reads += (uint64_t)n_ovf;
+			cap2 = std::max<uint32_t>(256, cap * 8);
+			for (;;) {
+				CS_TRY(e->d_out2.reserve((size_t)n_ovf * cap2));
+				CS_TRY(e->d_cnt2.reserve((size_t)n_ovf));
+				CS_TRY(e->d_tmp2.reserve((size_t)n_ovf * 4 + 16));
+				CS_TRY(launch_smem(e, par, d_off + b0, e->d_ovf.p, n_ovf, e->d_out2.p, e->d_cnt2.p, cap2, max_len));
+				HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, sizeof(unsigned long long), s));
+				// reuse the overflow counter to see whether any task still does not fit
+				hipLaunchKernelGGL(collect_overflow_kernel, dim3(grid_for(n_ovf, 256)), dim3(256), 0, s, e->d_cnt2.p, n_ovf, cap2, 0u,
+				                   (uint32_t *)e->d_tmp2.p, e->d_ctr.p + 2);
+				HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+				HIP_TRY(hipStreamSynchronize(s));
+				CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
+				e->st.bwt_queries += e->h_ctr.p[1]; e->st.bwt_calls += e->h_ctr.p[1];
+				HIP_TRY(hipMemsetAsync(e->d_ctr.p + 1, 0, sizeof(unsigned long long), s));
+				if (e->h_ctr.p[2] == 0) break;
+				if (cap2 >= (1u << 22)) return fail(CS_ERANGE, "a read produced more than 4M mems");
+				cap2 *= 8;
+			}
+			hipLaunchKernelGGL(patch_counts_kernel, dim3(grid_for(n_ovf, 256)), dim3(256), 0, s, e->d_cnt2.p, e->d_ovf.p, n_ovf, 0u, e->d_cnt.p);
+		}
+		// offsets of this sub-batch, continuing the running total
+		CS_TRY(scan_counts(e, e->d_cnt.p, e->d_mem_off.p + b0, (size_t)nb, total_mems));
+		HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_mem_off.p + b0 + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		uint64_t new_total = e->h_ctr.p[0];
+		CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
+		// mem_off already holds absolute offsets, so base_off = 0 and the per-read offset array is shifted by b0
+		hipLaunchKernelGGL(sort_compact_kernel, dim3(grid_for(nb, 128)), dim3(128), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_mem_off.p + b0,
+		                   (uint64_t)0, nb, (const uint32_t *)nullptr, e->d_mems.p);
+		if (n_ovf > 0)
+			hipLaunchKernelGGL(sort_compact_list_kernel, dim3(grid_for(n_ovf, 64)), dim3(64), 0, s, e->d_out2.p, e->d_cnt2.p, cap2, e->d_ovf.p,
+			                   n_ovf, e->d_mem_off.p + b0, e->d_mems.p);
+		HIP_TRY(hipGetLastError());
+		total_mems = new_total;
+	}
+	*n_mems_out = total_mems;
+
+	if (par->want_sal) { // comp_seed.cpp:2306-2347
+		CS_TRY(e->d_seed_off.reserve((size_t)n_reads + 2));
+		CS_TRY(e->d_seed_of_mem.reserve((size_t)total_mems + 2));
+		// per-mem slot counts are written into the tail of d_seed_of_mem's own storage via a temp
+		DevBuf<uint64_t> &som = e->d_seed_of_mem;
+		CS_TRY(e->d_tmp.reserve(((size_t)total_mems + 2) * 8 + 1024));
+		uint64_t *cnt64 = (uint64_t *)e->d_tmp.p;
+		HIP_TRY(hipEventRecord(e->ev[0], s));
+		HIP_TRY(hipMemsetAsync(cnt64 + total_mems, 0, 8, s));
+		if (total_mems)
+			hipLaunchKernelGGL(sal_count_kernel, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->d_mems.p, total_mems,
+			                   (uint32_t)par->max_occ, cnt64);
+		{ // scan needs its own temp storage: keep the counts where they are and scan with a second buffer
+			size_t tmp = 0;
+			HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, cnt64, som.p, (uint64_t)0, (size_t)total_mems + 1, rocprim::plus<uint64_t>(), s));
+			CS_TRY(e->d_tmp2.reserve(tmp + 16));
+			HIP_TRY(rocprim::exclusive_scan((void *)e->d_tmp2.p, tmp, cnt64, som.p, (uint64_t)0, (size_t)total_mems + 1, rocprim::plus<uint64_t>(), s));
+		}
+		HIP_TRY(hipMemcpyAsync(e->h_ctr.p, som.p + total_mems, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		uint64_t total_seeds = e->h_ctr.p[0];
+		CS_TRY(e->d_seeds.reserve((size_t)total_seeds + 16));
+		if (total_mems)
+			hipLaunchKernelGGL(sal_expand_kernel, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->d_mems.p, total_mems,
+			                   (uint32_t)par->max_occ, som.p, e->d_seeds.p);
+		if (total_seeds)
+			hipLaunchKernelGGL(sal_walk_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
+		hipLaunchKernelGGL(seed_off_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, e->d_mem_off.p, som.p, n_reads, e->d_seed_off.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(e->ev[1], s));
+		HIP_TRY(hipStreamSynchronize(s));
+		CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.sal_kernel_ms));
+		*n_seeds_out = total_seeds;
+		e->st.sal_queries += total_seeds; e->st.sal_calls += total_seeds;
+	}
+	HIP_TRY(hipEventRecord(e->ev[3], s));
+	HIP_TRY(hipStreamSynchronize(s));
+	CS_TRY(add_event_ms(e, e->ev[2], e->ev[3], &e->st.total_ms));
+	e->st.reads += (uint64_t)n_reads; e->st.bases += n_bases; e->st.mems += total_mems; e->st.seeds += *n_seeds_out;
+	return CS_OK;
+}
+
+extern "C" int cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases,
+                                           const uint64_t *d_offsets, uint64_t n_bases, cs_result_t *out)
+{
+	if (!e || !par || !out || n_reads < 0 || (n_reads > 0 && !d_offsets) || (n_bases > 0 && !d_bases))
+		return fail(CS_EINVAL, "cs_engine_seed_batch_device: bad argument");
+	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
+	HIP_TRY(hipSetDevice(e->device));
+	uint64_t nm = 0, ns = 0;
+	CS_TRY(seed_device_impl(e, par, n_reads, d_bases, d_offsets, n_bases, &nm, &ns));
+	out->n_reads = n_reads; out->n_mems = nm; out->n_seeds = ns;
+	out->mem_off = e->d_mem_off.p; out->mems = (const cs_intv_t *)e->d_mems.p;
+	out->seed_off = par->want_sal ? e->d_seed_off.p : nullptr;
+	out->seeds = par->want_sal ? (const cs_seed_t *)e->d_seeds.p : nullptr;
+	return CS_OK;
+}
+
+extern "C" int cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases,
+                                    const uint64_t *offsets, cs_result_t *out)
+{
+	if (!e || !par || !out || n_reads < 0 || (n_reads > 0 && !offsets)) return fail(CS_EINVAL, "cs_engine_seed_batch: bad argument");
+	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t s = e->stream;
+	uint64_t n_bases = 0;
+	if (n_reads > 0) {
+		if (offsets[0] != 0) return fail(CS_EINVAL, "offsets[0] must be 0");
+		n_bases = offsets[n_reads];
+		if (n_bases > 0 && !bases) return fail(CS_EINVAL, "bases is null");
+		CS_TRY(e->d_raw.reserve((size_t)n_bases + 64));
+		CS_TRY(e->d_off.reserve((size_t)n_reads + 1));
+		HIP_TRY(hipMemcpyAsync(e->d_raw.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, s));
+		HIP_TRY(hipMemcpyAsync(e->d_off.p, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+	}
+	uint64_t nm = 0, ns = 0;
+	CS_TRY(seed_device_impl(e, par, n_reads, e->d_raw.p, e->d_off.p, n_bases, &nm, &ns));
+	CS_TRY(e->h_mem_off.reserve((size_t)n_reads + 1));
+	CS_TRY(e->h_mems.reserve((size_t)nm + 1));
+	HIP_TRY(hipMemcpyAsync(e->h_mem_off.p, e->d_mem_off.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+	if (nm) HIP_TRY(hipMemcpyAsync(e->h_mems.p, e->d_mems.p, (size_t)nm * sizeof(OutMem), hipMemcpyDeviceToHost, s));
+	if (par->want_sal) {
+		CS_TRY(e->h_seed_off.reserve((size_t)n_reads + 1));
+		CS_TRY(e->h_seeds.reserve((size_t)ns + 1));
+		HIP_TRY(hipMemcpyAsync(e->h_seed_off.p, e->d_seed_off.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+		if (ns) HIP_TRY(hipMemcpyAsync(e->h_seeds.p, e->d_seeds.p, (size_t)ns * sizeof(OutSeed), hipMemcpyDeviceToHost, s));
+	}
+	HIP_TRY(hipStreamSynchronize(s));
+	out->n_reads = n_reads; out->n_mems = nm; out->n_seeds = ns;
+	out->mem_off = e->h_mem_off.p; out->mems = (const cs_intv_t *)e->h_mems.p;
+	out->seed_off = par->want_sal ? e->h_seed_off.p : nullptr;
+	out->seeds = par->want_sal ? (const cs_seed_t *)e->h_seeds.p : nullptr;
+	return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ primitives (tests)
+template <typename In, typename Out, typename Launch>
+static int run_prim(cs_engine *e, int64_t n, const In *h_in, size_t in_per, Out *h_out, size_t out_per, const uint8_t *h_flag, Launch launch)
+{
+	if (!e || n < 0 || (n > 0 && (!h_in || !h_out))) return fail(CS_EINVAL, "bad argument");
+	if (n == 0) return CS_OK;
+	HIP_TRY(hipSetDevice(e->device));
+	In *d_in = nullptr; Out *d_out = nullptr; uint8_t *d_flag = nullptr;
+	HIP_TRY(hipMalloc((void **)&d_in, (size_t)n * in_per * sizeof(In)));
+	HIP_TRY(hipMalloc((void **)&d_out, (size_t)n * out_per * sizeof(Out)));
+	if (h_flag) { HIP_TRY(hipMalloc((void **)&d_flag, (size_t)n)); HIP_TRY(hipMemcpy(d_flag, h_flag, (size_t)n, hipMemcpyHostToDevice)); }
+	HIP_TRY(hipMemcpy(d_in, h_in, (size_t)n * in_per * sizeof(In), hipMemcpyHostToDevice));
+	launch(d_in, d_flag, d_out);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	HIP_TRY(hipMemcpy(h_out, d_out, (size_t)n * out_per * sizeof(Out), hipMemcpyDeviceToHost));
+	(void)hipFree(d_in); (void)hipFree(d_out); if (d_flag) (void)hipFree(d_flag);
+	return CS_OK;
+}
+
+extern "C" int cs_engine_occ4(cs_engine_t *e, int64_t n, const uint64_t *k, uint64_t *cnt4)
+{
+	return run_prim<uint64_t, uint64_t>(e, n, k, 1, cnt4, 4, nullptr, [&](const uint64_t *di, const uint8_t *, uint64_t *dout) {
+		hipLaunchKernelGGL(occ4_kernel, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, e->ix, di, dout, n);
+	});
+}
+extern "C" int cs_engine_extend(cs_engine_t *e, int64_t n, const cs_intv_t *ik, const uint8_t *is_back, cs_intv_t *ok4)
+{
+	if (n > 0 && !is_back) return fail(CS_EINVAL, "is_back is null");
+	return run_prim<OutMem, OutMem>(e, n, (const OutMem *)ik, 1, (OutMem *)ok4, 4, is_back, [&](const OutMem *di, const uint8_t *df, OutMem *dout) {
+		hipLaunchKernelGGL(extend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, e->ix, di, df, dout, n);
+	});
+}
+extern "C" int cs_engine_sa(cs_engine_t *e, int64_t n, const uint64_t *k, uint64_t *sa)
+{
+	if (e) for (int64_t i = 0; i < n; ++i) if (k && k[i] > e->ix.seq_len) return fail(CS_EINVAL, "SA row out of range");
+	return run_prim<uint64_t, uint64_t>(e, n, k, 1, sa, 1, nullptr, [&](const uint64_t *di, const uint8_t *, uint64_t *dout) {
+		hipLaunchKernelGGL(sa_kernel, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, e->ix, di, dout, n);
+	});
+}
+
+// ------------------------------------------------------------------------------------------------ device memory helpers
+extern "C" int cs_device_alloc(cs_engine_t *e, size_t bytes, void **dptr)
+{
+	if (!e || !dptr) return fail(CS_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+	return CS_OK;
+}
+extern "C" int cs_device_free(cs_engine_t *e, void *dptr)
+{
+	if (!e) return fail(CS_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipFree(dptr));
+	return CS_OK;
+}
+extern "C" int cs_device_upload(cs_engine_t *e, void *dst, const void *src, size_t bytes)
+{
+	if (!e || (bytes && (!dst || !src))) return fail(CS_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return CS_OK;
+}
+extern "C" int cs_device_download(cs_engine_t *e, void *dst, const void *src, size_t bytes)
+{
+	if (!e || (bytes && (!dst || !src))) return fail(CS_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return CS_OK;
+}
+extern "C" int cs_device_sync(cs_engine_t *e)
+{
+	if (!e) return fail(CS_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return CS_OK;
+}

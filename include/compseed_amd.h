@@ -1,0 +1,139 @@
+/* compseed_amd.h -- C ABI of the MI355X-native compressive SMEM seeding engine.
+ *
+ * This is the drop-in boundary for ONE path of i-xiaohu/CompSeed: per-read SMEM collection over the FM-index
+ * plus the suffix-array lookup that turns the intervals into seeds, i.e. the two blocks
+ *     "Collect exact matches"  mapping/comp_seed.cpp:2247-2304   (== mem_collect_intv, mapping/bwamem.c:218-272)
+ *     "SAL"                    mapping/comp_seed.cpp:2306-2347
+ * of seed_and_extend(), called once per chunk from mem_process_seqs (comp_seed.cpp:2527).  The reference has no
+ * FFI of its own (everything is statically linked); INTEGRATION.md shows the 20-line patch that makes
+ * seed_and_extend() consume this API.  Plain C types only: no torch, no HIP types, no C++.
+ *
+ * All functions return 0 on success or a negative CS_E* code; cs_last_error() gives the message for the calling
+ * thread.  Nothing in here aborts the process (the reference aborts/exits on error: bwalib/utils.c:92-124).
+ * An engine is bound to one GPU and must be driven by one host thread at a time; engines are independent.
+ */
+#ifndef COMPSEED_AMD_H
+#define COMPSEED_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_OK          0
+#define CS_EINVAL     -1   /* bad argument                                   */
+#define CS_EIO        -2   /* index file missing / truncated / inconsistent  */
+#define CS_ENOMEM     -3   /* host or device allocation failed               */
+#define CS_EDEVICE    -4   /* HIP runtime error (no GPU, launch failure ...) */
+#define CS_ERANGE     -5   /* index or read too large for the device layout  */
+
+/* bi-interval; identical layout and meaning to bwtintv_t (FM_index/bwt.h:62-64):
+ * x0 = SA start of the match, x1 = SA start of its reverse complement, x2 = occurrences,
+ * info = (query begin << 32) | query end for a finished mem (comp_seed.cpp:127). */
+typedef struct { uint64_t x0, x1, x2, info; } cs_intv_t;
+
+/* seed = the fields of mem_seed_t that seeding fills (mapping/comp_seed.h:77-83; score == len, aln unused) */
+typedef struct { int64_t rbeg; int32_t qbeg, len; } cs_seed_t;
+
+/* read-only view of the FM-index arrays a bwt_t holds (FM_index/bwt.h:48-60).  `bwt` is the interleaved
+ * Occ/BWT array exactly as stored in <prefix>.bwt (64-byte blocks, bwt.h:73-80); `sa` is the sampled suffix
+ * array with sa[0] == (uint64_t)-1 as bwt_restore_sa leaves it (bwt.c:437). */
+typedef struct {
+	uint64_t primary;
+	uint64_t L2[5];
+	uint64_t seq_len;
+	uint64_t bwt_size;      /* number of 32-bit words in bwt */
+	const uint32_t *bwt;
+	uint64_t sa_intv;       /* power of two, 32 for bwaidx-built indexes */
+	uint64_t n_sa;
+	const uint64_t *sa;
+} cs_index_view_t;
+
+/* the mem_opt_t fields the seeding path reads (mapping/comp_seed.h:50-59), CLI flags in brackets */
+typedef struct {
+	int32_t  min_seed_len;   /* [-k] 19   */
+	float    split_factor;   /* [-r] 1.5  */
+	int32_t  split_width;    /* [-s] 10   */
+	int32_t  max_occ;        /* [-c] 500  */
+	uint64_t max_mem_intv;   /* [-y] 20   */
+	int32_t  want_sal;       /* 1: also produce seeds (SAL block), 0: mems only */
+	int32_t  sst_mode;       /* 0: on-device SST cache off, 1: on (results identical; only speed/counters differ) */
+} cs_params_t;
+
+/* CSR result of one batch.  Read r owns mems[mem_off[r] .. mem_off[r+1]) sorted by info (comp_seed.cpp:2301) and
+ * seeds[seed_off[r] .. seed_off[r+1]) in mem-then-slot order (comp_seed.cpp:2311-2325).  The arrays belong to the
+ * engine and stay valid until the next seed call on the same engine or its destruction. */
+typedef struct {
+	int64_t   n_reads;
+	uint64_t  n_mems, n_seeds;
+	const uint64_t  *mem_off;   /* n_reads + 1 */
+	const cs_intv_t *mems;
+	const uint64_t  *seed_off;  /* n_reads + 1; NULL when want_sal == 0 */
+	const cs_seed_t *seeds;
+} cs_result_t;
+
+/* counters in the spirit of display_profile (main.cpp:203-214), accumulated over the engine's lifetime */
+typedef struct {
+	uint64_t reads, bases, mems, seeds;
+	uint64_t bwt_queries;      /* bwt_extend queries issued on the device ("BWT-extend queries")          */
+	uint64_t bwt_calls;        /* of those, served from HBM/L2, i.e. not by the on-device SST               */
+	uint64_t sal_queries;      /* SA slots requested                                                        */
+	uint64_t sal_calls;        /* SA slots actually walked (after on-device dedup)                          */
+	uint64_t overflow_reads;   /* reads that needed the large-capacity second pass                          */
+	double   seed_kernel_ms;   /* accumulated HIP-event time of the SMEM kernel(s)                          */
+	double   sal_kernel_ms;    /* ... of the SAL kernels                                                    */
+	double   total_ms;         /* ... of whole seed calls, first launch to last                             */
+	uint64_t seed_kernel_launches;
+} cs_stats_t;
+
+typedef struct cs_index  cs_index_t;   /* host copy of an index loaded from files */
+typedef struct cs_engine cs_engine_t;
+
+const char *cs_last_error(void);
+const char *cs_version(void);
+
+void cs_params_default(cs_params_t *p);                     /* mem_opt_init, comp_seed.cpp:26-58 */
+
+/* ---- index files: <prefix>.bwt and <prefix>.sa in the reference's formats (bwt_restore_bwt / bwt_restore_sa,
+ *      FM_index/bwt.c:421-462; prefix inference as bwa_idx_infer_prefix, bwalib/bwa.c:244) */
+int  cs_index_load(const char *prefix, cs_index_t **out);
+int  cs_index_view(const cs_index_t *idx, cs_index_view_t *view);
+void cs_index_free(cs_index_t *idx);
+
+/* ---- engine: uploads the index to GPU `device` once (replaces bwa_idx_load_from_shm's role: HBM residency) */
+int  cs_device_count(int *n);
+int  cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out);
+void cs_engine_destroy(cs_engine_t *e);
+
+/* ---- the hot path.  `bases` holds the reads back to back (ASCII or already nt4-coded 0..4, as CompSeed accepts:
+ *      comp_seed.cpp:2258-2260); read r is bases[offsets[r] .. offsets[r+1]).  The caller's buffers are not modified
+ *      (the reference overwrites seq in place).  Host variant: pointers are host memory, results land in pinned host
+ *      memory.  Device variant: pointers are device memory on the engine's GPU and the result arrays are device
+ *      pointers (no PCIe traffic inside the call). */
+int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
+                          const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
+int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
+                                 const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases, cs_result_t *out);
+
+int  cs_engine_stats(const cs_engine_t *e, cs_stats_t *st);
+void cs_engine_reset_stats(cs_engine_t *e);
+
+/* ---- batched primitives on the device index, for parity tests of the building blocks (host pointers):
+ *      bwt_occ4 (bwt.c:169), bwt_extend (bwt.c:262; ok is n x 4 intervals, info untouched = 0), bwt_sa (bwt.c:86) */
+int  cs_engine_occ4(cs_engine_t *e, int64_t n, const uint64_t *k, uint64_t *cnt4);
+int  cs_engine_extend(cs_engine_t *e, int64_t n, const cs_intv_t *ik, const uint8_t *is_back, cs_intv_t *ok4);
+int  cs_engine_sa(cs_engine_t *e, int64_t n, const uint64_t *k, uint64_t *sa);
+
+/* ---- device memory helpers so that a caller without its own HIP code can stage inputs for the device variant */
+int  cs_device_alloc(cs_engine_t *e, size_t bytes, void **dptr);
+int  cs_device_free(cs_engine_t *e, void *dptr);
+int  cs_device_upload(cs_engine_t *e, void *dst, const void *src, size_t bytes);
+int  cs_device_download(cs_engine_t *e, void *dst, const void *src, size_t bytes);
+int  cs_device_sync(cs_engine_t *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMPSEED_AMD_H */

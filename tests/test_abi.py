@@ -1,0 +1,82 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports exactly the declared C ABI."""
+import os
+import re
+
+import pytest
+
+import _data
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import compseed_amd as ca
+    if not os.path.exists(ca.lib_path()):
+        ca.build_library()
+    return ca.load_library()
+
+
+def test_header_symbols_are_exported(lib):
+    import compseed_amd.binding as b
+    hdr = open(os.path.join(ROOT, "include", "compseed_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(b.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_index_loader_reads_reference_formats(lib):
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    f = _data.load_bwt_files()
+    assert ix.view.primary == f["primary"] and ix.view.seq_len == f["seq_len"]
+    assert list(ix.view.L2) == [0] + [int(x) for x in f["L2"]]
+    assert ix.view.bwt_size == f["bwt"].size and ix.view.n_sa == f["sa"].size and ix.view.sa_intv == 32
+    ix.close()
+
+
+def test_index_loader_errors(lib, tmp_path):
+    import compseed_amd as ca
+    with pytest.raises(ca.CSError) as ei:
+        ca.Index.load(str(tmp_path / "nope"))
+    assert ei.value.code == -2
+    # SA that belongs to another BWT: "SA-BWT inconsistency" (bwt.c:429)
+    import shutil
+    shutil.copy(_data.PREFIX + ".bwt", tmp_path / "x.bwt")
+    raw = bytearray(open(_data.PREFIX + ".sa", "rb").read())
+    raw[0] ^= 1
+    open(tmp_path / "x.sa", "wb").write(raw)
+    with pytest.raises(ca.CSError) as ei:
+        ca.Index.load(str(tmp_path / "x"))
+    assert "inconsistency" in str(ei.value)
+
+
+def test_no_gpu_fails_loudly(lib):
+    """The product has no CPU path: on a box without a GPU engine creation must raise, never fall back."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    with pytest.raises(ca.CSError) as ei:
+        ca.Engine(ix, 0)
+    assert ei.value.code == -4
+    ix.close()
+
+
+def test_params_default(lib):
+    import compseed_amd as ca
+    p = ca.Params(k=1, r=9, s=9, c=9, y=9)
+    lib.cs_params_default(p)
+    assert (p.min_seed_len, p.split_width, p.max_occ, p.max_mem_intv, p.want_sal) == (19, 10, 500, 20, 1)
+    assert abs(p.split_factor - 1.5) < 1e-9
+
+
+def test_product_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under compseed_amd/ may include, link or load it."""
+    for base, _, files in os.walk(os.path.join(ROOT, "compseed_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(base, f), errors="replace").read()
+                assert "cs_oracle" not in txt and "libcsoracle" not in txt and "oracle/" not in txt, os.path.join(base, f)

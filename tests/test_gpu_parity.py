@@ -1,0 +1,126 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the golden vectors of the real reference
+and against the oracle (CPU restatement) on the same inputs.  Bit-exact: these are integers."""
+import os
+
+import numpy as np
+import pytest
+
+import _data
+import _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0)
+    yield e
+    e.close()
+    ix.close()
+
+
+def test_primitives_known_answers(eng):
+    import compseed_amd as ca
+    z = np.load(os.path.join(_data.GOLD, "prims.npz"))
+    occ = z["occ4"]
+    assert np.array_equal(eng.occ4(occ[:, 0]), occ[:, 1:5])          # bwt_occ4, bwt.c:169
+    ext = z["ext"]
+    ik = np.zeros(ext.shape[0], dtype=ca.INTV_DT)
+    ik["x0"], ik["x1"], ik["x2"] = ext[:, 0], ext[:, 1], ext[:, 2]
+    got = eng.extend(ik, ext[:, 3].astype(np.uint8))                    # bwt_extend, bwt.c:262
+    want = ext[:, 4:].reshape(-1, 4, 3)
+    assert np.array_equal(got["x0"], want[:, :, 0])
+    assert np.array_equal(got["x1"], want[:, :, 1])
+    assert np.array_equal(got["x2"], want[:, :, 2])
+    assert not got["info"].any()                                        # single-child path == four-child path
+    sa = z["sa"]
+    assert np.array_equal(eng.sa(sa[:, 0]), sa[:, 1])                   # bwt_sa, bwt.c:86
+
+
+def _check_against_golden(res, z):
+    assert np.array_equal(res.mem_off, z["mem_off"])
+    m = res.mems
+    assert np.array_equal(np.stack([m["x0"], m["x1"], m["x2"], m["info"]], axis=1), z["mems"])
+    assert np.array_equal(res.seed_off, z["seed_off"])
+    assert np.array_equal(res.seeds["rbeg"], z["seed_rbeg"])
+    assert np.array_equal(res.seeds["qbeg"], z["seed_qbeg"])
+    assert np.array_equal(res.seeds["len"], z["seed_len"])
+
+
+@pytest.mark.parametrize("name,pname", _data.golden_runs())
+def test_golden_seeds(eng, name, pname):
+    import compseed_amd as ca
+    z, kw = _data.load_golden(name, pname)
+    bases, off = _data.load_reads(name)
+    eng.reset_stats()
+    res = eng.seed_batch(bases, off, ca.Params(**kw))
+    _check_against_golden(res, z)
+    st = eng.stats()
+    assert st["bwt_queries"] >= int(z["counters"][3])   # == unless reads overflowed into the second pass
+    if st["overflow_reads"] == 0:
+        assert st["bwt_queries"] == int(z["counters"][3])
+    assert st["sal_queries"] == int(z["counters"][5])
+
+
+def test_device_variant_equals_host_variant(eng):
+    import compseed_amd as ca
+    bases, off = _data.load_reads("sorted150")
+    host = eng.seed_batch(bases, off)
+    d_b = eng.alloc(bases.nbytes + 64); d_o = eng.alloc(off.nbytes)
+    eng.upload(d_b, bases); eng.upload(d_o, off)
+    dev = eng.seed_batch_device(d_b, d_o, off.size - 1, bases.size)
+    assert dev.n_mems == host.n_mems and dev.n_seeds == host.n_seeds
+    mo = eng.download(dev.ptr["mem_off"], np.uint64, off.size)
+    mm = eng.download(dev.ptr["mems"], ca.INTV_DT, dev.n_mems)
+    ss = eng.download(dev.ptr["seeds"], ca.SEED_DT, dev.n_seeds)
+    assert np.array_equal(mo, host.mem_off) and np.array_equal(mm, host.mems) and np.array_equal(ss, host.seeds)
+    # the caller's read buffer is not modified (the reference overwrites it in place, comp_seed.cpp:2258)
+    assert np.array_equal(eng.download(d_b, np.uint8, bases.size), bases)
+    eng.free(d_b); eng.free(d_o)
+
+
+def test_empty_and_degenerate_batches(eng):
+    r = eng.seed_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert r.n_reads == 0 and r.n_mems == 0 and r.n_seeds == 0
+    bases, off = _data.pack_reads([b"", b"", b""])
+    r = eng.seed_batch(bases, off)
+    assert r.n_mems == 0 and list(r.mem_off) == [0, 0, 0, 0]
+    bases, off = _data.pack_reads([b"N" * 100, b"ACGT"])
+    r = eng.seed_batch(bases, off)
+    assert r.n_mems == 0
+
+
+def test_errors_are_codes_not_aborts(eng):
+    import compseed_amd as ca
+    bases, off = _data.pack_reads([b"A" * 70000])
+    with pytest.raises(ca.CSError) as ei:
+        eng.seed_batch(bases, off)
+    assert ei.value.code == -5  # CS_ERANGE: MAX_READ_LEN 65535 (main.cpp:83-86 aborts there)
+    with pytest.raises(ca.CSError):
+        eng.seed_batch(np.zeros(10, np.uint8), np.array([0, 8, 4], np.uint64))
+
+
+def test_matches_oracle_on_fresh_random_reads(eng):
+    """reads never seen by the golden generator: substrings of the fixture genome with heavy mutation + junk"""
+    rng = np.random.default_rng(5)
+    import gzip
+    fa = gzip.open(os.path.join(_data.GOLD, "ref.fa.gz")).read().decode().split("\n")
+    g = "".join(l for l in fa if not l.startswith(">")).replace("N", "A")
+    reads = []
+    for _ in range(4000):
+        ln = int(rng.integers(20, 200)); p = int(rng.integers(0, len(g) - ln))
+        r = np.frombuffer(g[p:p + ln].encode(), dtype=np.uint8).copy()
+        mut = rng.random(ln) < rng.choice([0.0, 0.01, 0.03, 0.1])
+        r[mut] = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, int(mut.sum()))]
+        reads.append(r.tobytes())
+    bases, off = _data.pack_reads(reads)
+    o = _oracle.OracleIndex(_data.PREFIX)
+    for kw in (dict(), dict(k=15, r=1.0, y=30, c=100, s=30)):
+        want = o.seed_batch(bases, off, _oracle.make_params(**kw), mode=0, threads=4)
+        import compseed_amd as ca
+        got = eng.seed_batch(bases, off, ca.Params(**kw))
+        assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"])
+        assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
+    o.close()
