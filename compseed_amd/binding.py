@@ -10,7 +10,7 @@ INTV_DT = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")
 SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])               # cs_seed_t
 
 # every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
-SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free",
+SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build", "cs_index_save",
            "cs_device_count", "cs_engine_create", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_device_alloc", "cs_device_free", "cs_device_upload",
@@ -87,6 +87,8 @@ def load_library():
     L.cs_index_view.argtypes = [vp, C.POINTER(IndexView)]
     L.cs_index_free.argtypes = [vp]
     L.cs_index_free.restype = None
+    L.cs_index_build.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.cs_index_save.argtypes = [vp, C.c_char_p]
     L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
     L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
     L.cs_engine_destroy.argtypes = [vp]
@@ -149,6 +151,29 @@ class Index:
         v.n_sa = sa.size
         v.sa = sa.ctypes.data
         return self
+
+    @classmethod
+    def build(cls, fwd_nt4, device=0):
+        """Build the FM-index of a genome (forward strand, codes 0..3) on the GPU (cs_index_build)."""
+        self = cls()
+        L = load_library()
+        g = np.ascontiguousarray(fwd_nt4, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(L.cs_index_build(g.ctypes.data, g.size, int(device), C.byref(h)))
+        self._handle = h
+        _check(L.cs_index_view(h, C.byref(self.view)))
+        return self
+
+    def save(self, prefix):
+        """Write <prefix>.bwt / <prefix>.sa in the reference's formats (cs_index_save)."""
+        if self._handle is None:
+            raise ValueError("only file- or GPU-built indexes can be saved")
+        _check(load_library().cs_index_save(self._handle, os.fsencode(prefix)))
+
+    def arrays(self):
+        """numpy views (copies) of the bwt words and the sampled SA"""
+        v = self.view
+        return _view(v.bwt, "<u4", int(v.bwt_size)), _view(v.sa, "<u8", int(v.n_sa))
 
     def close(self):
         if self._handle is not None:

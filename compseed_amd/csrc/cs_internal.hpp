@@ -1,0 +1,13 @@
+// cs_internal.hpp -- declarations shared by the translation units of libcompseed_amd.so (not part of the C ABI)
+#pragma once
+#include "../../include/compseed_amd.h"
+#include <string>
+#include <vector>
+
+struct cs_index { // host copy of an index: the arrays behind a cs_index_view_t
+	cs_index_view_t v;
+	std::vector<uint32_t> bwt;
+	std::vector<uint64_t> sa;
+};
+
+int cs_fail_(int code, const std::string &msg); // records the calling thread's error message, returns code

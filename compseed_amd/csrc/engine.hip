@@ -2,7 +2,7 @@
 //
 // Host-side counterpart of mem_process_seqs -> seed_and_extend (mapping/comp_seed.cpp:2527, 2242) for the seeding
 // and SAL blocks only.  No CPU fallback exists: without a HIP device every entry point fails with CS_EDEVICE.
-#include "../../include/compseed_amd.h"
+#include "cs_internal.hpp"
 #include "seed_kernels.hpp"
 
 #include <algorithm>
@@ -20,6 +20,7 @@ using namespace csd;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+int cs_fail_(int code, const std::string &msg) { return fail(code, msg); }
 
 #define HIP_TRY(expr)                                                                              \
 	do {                                                                                           \
@@ -75,12 +76,6 @@ template <typename T> struct PinBuf {
 		return CS_OK;
 	}
 	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct cs_index {
-	cs_index_view_t v;
-	std::vector<uint32_t> bwt;
-	std::vector<uint64_t> sa;
 };
 
 struct cs_engine {

@@ -102,6 +102,13 @@ int  cs_index_load(const char *prefix, cs_index_t **out);
 int  cs_index_view(const cs_index_t *idx, cs_index_view_t *view);
 void cs_index_free(cs_index_t *idx);
 
+/* ---- index construction on the GPU (replaces `bwaidx`, FM_index/index_main.c:257-325, for the .bwt/.sa pair):
+ *      `fwd_nt4` = forward strand, one base per byte, codes 0..3 (ambiguous bases already replaced, as
+ *      bns_fasta2bntseq does with lrand48, bntseq.c:295); the reverse complement is appended internally.
+ *      cs_index_save writes <prefix>.bwt / <prefix>.sa byte-identical to bwt_dump_bwt / bwt_dump_sa (bwt.c:385-407). */
+int  cs_index_build(const uint8_t *fwd_nt4, uint64_t l_pac, int device, cs_index_t **out);
+int  cs_index_save(const cs_index_t *idx, const char *prefix);
+
 /* ---- engine: uploads the index to GPU `device` once (replaces bwa_idx_load_from_shm's role: HBM residency) */
 int  cs_device_count(int *n);
 int  cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out);

@@ -59,3 +59,15 @@ def load_bwt_files(prefix=PREFIX):
     sa = s[6:].copy()
     sa[0] = np.uint64(2**64 - 1)
     return dict(primary=primary, L2=L2, bwt=words, sa=sa, sa_intv=sa_intv, seq_len=int(L2[3]))
+
+
+def load_pac_forward(prefix=PREFIX):
+    """forward strand from <prefix>.pac (2 bits/base, first base in the top bits, bntseq.c:236-237; the last byte is
+    l_pac % 4 and a zero byte precedes it when l_pac % 4 == 0, bntseq.c:316-324) -> uint8 codes 0..3"""
+    raw = np.fromfile(prefix + ".pac", dtype=np.uint8)
+    l_pac = (raw.size - 2) * 4 + int(raw[-1]) if raw[-1] else (raw.size - 2) * 4
+    if raw[-1]:
+        l_pac = (raw.size - 2) * 4 + int(raw[-1])
+    body = raw[:-1]
+    codes = np.stack([(body >> 6) & 3, (body >> 4) & 3, (body >> 2) & 3, body & 3], axis=1).reshape(-1)
+    return codes[:l_pac].astype(np.uint8)

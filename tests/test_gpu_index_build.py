@@ -1,0 +1,70 @@
+"""GPU index builder (cs_index_build) against the reference-built fixture: .bwt/.sa must be byte-identical."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _data
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pac_roundtrip_matches_fasta():
+    import gzip
+    fa = gzip.open(os.path.join(_data.GOLD, "ref.fa.gz")).read().decode().split("\n")
+    g = "".join(l for l in fa if not l.startswith(">"))
+    codes = _data.load_pac_forward()
+    assert codes.size == len(g)
+    lut = {"A": 0, "C": 1, "G": 2, "T": 3}
+    want = np.array([lut.get(c, -1) for c in g])
+    known = want >= 0
+    assert np.array_equal(codes[known], want[known])  # N positions hold lrand48 bases (bntseq.c:295)
+
+
+def test_built_index_is_byte_identical_to_bwaidx(tmp_path):
+    import compseed_amd as ca
+    fwd = _data.load_pac_forward()
+    ix = ca.Index.build(fwd, 0)
+    f = _data.load_bwt_files()
+    assert ix.view.primary == f["primary"]
+    assert list(ix.view.L2)[1:] == [int(x) for x in f["L2"]]
+    bwt, sa = ix.arrays()
+    assert np.array_equal(bwt, f["bwt"])
+    assert np.array_equal(sa, f["sa"])
+    ix.save(str(tmp_path / "mine"))
+    man = json.load(open(os.path.join(os.path.dirname(_data.GOLD), "MANIFEST.json")))["md5"]
+    for ext in ("bwt", "sa"):
+        assert hashlib.md5(open(tmp_path / ("mine." + ext), "rb").read()).hexdigest() == man["g1/ref." + ext]
+    ix.close()
+
+
+def test_builder_on_adversarial_texts():
+    """long runs, tandem repeats and tiny genomes: the doubling rounds must converge and agree with a naive suffix sort"""
+    import compseed_amd as ca
+    rng = np.random.default_rng(3)
+    cases = [np.zeros(1, np.uint8), np.array([0, 1, 2, 3], np.uint8), np.zeros(500, np.uint8),
+             np.tile(np.array([0, 1], np.uint8), 300), np.tile(rng.integers(0, 4, 37).astype(np.uint8), 40),
+             rng.integers(0, 4, 5000).astype(np.uint8),
+             np.concatenate([rng.integers(0, 4, 700), np.full(900, 3), rng.integers(0, 4, 300)]).astype(np.uint8)]
+    for g in cases:
+        T = np.concatenate([g, 3 - g[::-1]])
+        n = T.size
+        s = T.tobytes()
+        sa = sorted(range(n + 1), key=lambda i: s[i:])           # $ = end of string sorts first
+        primary = sa.index(0)
+        bw = [T[i - 1] for i in sa if i != 0]
+        ix = ca.Index.build(g, 0)
+        assert ix.view.primary == primary and ix.view.seq_len == n
+        words, samp = ix.arrays()
+        got = []
+        for b in range((n + 127) // 128):
+            for w in range(8):
+                for t in range(16):
+                    pos = b * 128 + w * 16 + t
+                    if pos < n:
+                        got.append((int(words[b * 16 + 8 + w]) >> ((15 - t) * 2)) & 3)
+        assert got == [int(x) for x in bw]
+        assert [int(x) for x in samp[1:]] == [sa[r] for r in range(32, n + 1, 32)]
+        ix.close()
