@@ -337,7 +337,7 @@ static int launch_smem(cs_engine *e, const cs_params_t *par, const uint64_t *d_o
 	hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, SMEM_LEP_LDS>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[1], e->stream));
-	e->st.seed_kernel_launches++;
+	if (d_ids) e->st.overflow_kernel_launches++; else e->st.seed_kernel_launches++;
 	return CS_OK;
 }
 
@@ -417,7 +417,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 				                   (uint32_t *)e->d_tmp2.p, e->d_ctr.p + 2);
 				HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 				HIP_TRY(hipStreamSynchronize(s));
-				CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
+				CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.overflow_kernel_ms));
 				e->st.bwt_queries += e->h_ctr.p[1]; e->st.bwt_calls += e->h_ctr.p[1];
 				HIP_TRY(hipMemsetAsync(e->d_ctr.p + 1, 0, sizeof(unsigned long long), s));
 				if (e->h_ctr.p[2] == 0) break;

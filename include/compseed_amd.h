@@ -82,10 +82,12 @@ typedef struct {
 	uint64_t sal_queries;      /* SA slots requested                                                        */
 	uint64_t sal_calls;        /* SA slots actually walked (after on-device dedup)                          */
 	uint64_t overflow_reads;   /* reads that needed the large-capacity second pass                          */
-	double   seed_kernel_ms;   /* accumulated HIP-event time of the SMEM kernel(s)                          */
+	double   seed_kernel_ms;   /* accumulated HIP-event time of the first-pass SMEM kernel launches         */
 	double   sal_kernel_ms;    /* ... of the SAL kernels                                                    */
 	double   total_ms;         /* ... of whole seed calls, first launch to last                             */
 	uint64_t seed_kernel_launches;
+	double   overflow_kernel_ms;       /* ... of the second-pass SMEM launches over overflowed reads        */
+	uint64_t overflow_kernel_launches;
 } cs_stats_t;
 
 typedef struct cs_index  cs_index_t;   /* host copy of an index loaded from files */
