@@ -13,7 +13,7 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build", "cs_index_save",
            "cs_device_count", "cs_engine_create", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
-           "cs_engine_extend", "cs_engine_sa", "cs_device_alloc", "cs_device_free", "cs_device_upload",
+           "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync"]
 
 
@@ -102,6 +102,7 @@ def load_library():
     L.cs_engine_occ4.argtypes = [vp, i64, vp, vp]
     L.cs_engine_extend.argtypes = [vp, i64, vp, vp, vp]
     L.cs_engine_sa.argtypes = [vp, i64, vp, vp]
+    L.cs_engine_probe_random_lines.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.cs_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.cs_device_free.argtypes = [vp, vp]
     L.cs_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
@@ -276,6 +277,12 @@ class Engine:
         out = np.zeros(k.size, dtype=np.uint64)
         _check(self._L.cs_engine_sa(self._h, k.size, k.ctypes.data, out.ctypes.data))
         return out
+
+    def probe_random_lines(self, waves_per_simd=8, steps=2000):
+        """64-byte random Occ-block reads per second in dependent chains (cs_engine_probe_random_lines)"""
+        out = C.c_double()
+        _check(self._L.cs_engine_probe_random_lines(self._h, waves_per_simd, steps, C.byref(out)))
+        return out.value
 
     # ---- device memory helpers
     def alloc(self, nbytes):

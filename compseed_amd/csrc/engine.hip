@@ -18,6 +18,7 @@
 
 using namespace csd;
 
+static int g_lep_lds = 20; // LEP entries per lane kept in LDS (CS_LEP_LDS = 20 | 13 | 10)
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 int cs_fail_(int code, const std::string &msg) { return fail(code, msg); }
@@ -85,6 +86,7 @@ struct cs_engine {
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
+	DevBuf<uint32_t> d_fsa32; DevBuf<uint64_t> d_fsa64; // full suffix array (one of the two)
 	// inputs
 	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
 	// SMEM stage
@@ -97,7 +99,7 @@ struct cs_engine {
 	PinBuf<uint64_t> h_mem_off, h_seed_off; PinBuf<OutMem> h_mems; PinBuf<OutSeed> h_seeds;
 	PinBuf<unsigned long long> h_ctr;
 	cs_stats_t st{};
-	uint32_t cap = 32;          // mems per read kept by the first pass
+	uint32_t cap = 64;          // mems per read kept by the first pass
 	size_t max_raw_bytes = (size_t)24 << 30;
 	int blocks_per_cu = 2;
 };
@@ -209,6 +211,32 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	ix.sa_mask = (uint32_t)(v->sa_intv - 1);
 	ix.sa_shift = (uint32_t)__builtin_ctzll(v->sa_intv);
 
+	// full suffix array in HBM (4 B/row below 2^32 rows, else 8 B/row): 50 GB for hg19 of the 288 GB on board
+	ix.fsa32 = nullptr; ix.fsa64 = nullptr;
+	const char *fs = getenv("CS_FULL_SA");
+	if (!fs || atoi(fs) != 0) {
+		uint64_t rows = v->seq_len + 1;
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		bool small = rows < 0xffffffffull;
+		size_t need = (size_t)rows * (small ? 4 : 8);
+		if (need + ((size_t)8 << 30) < free_b) {
+			unsigned grid = (unsigned)((v->n_sa + 255) / 256);
+			if (small) {
+				CS_TRY(e->d_fsa32.reserve((size_t)rows + 16));
+				hipLaunchKernelGGL(sa_fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, e->stream, ix, e->d_fsa32.p);
+				HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
+				ix.fsa32 = e->d_fsa32.p;
+			} else {
+				CS_TRY(e->d_fsa64.reserve((size_t)rows + 16));
+				hipLaunchKernelGGL(sa_fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, e->stream, ix, e->d_fsa64.p);
+				HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
+				ix.fsa64 = e->d_fsa64.p;
+			}
+		}
+	}
+
+	if (const char *s = getenv("CS_LEP_LDS")) { int v = atoi(s); g_lep_lds = (v == 10 || v == 13) ? v : 20; }
 	if (const char *s = getenv("CS_MEM_CAP")) { int c = atoi(s); if (c >= 1 && c <= 4096) e->cap = (uint32_t)c; }
 	if (const char *s = getenv("CS_MAX_RAW_MB")) { long m = atol(s); if (m >= 1) e->max_raw_bytes = (size_t)m << 20; }
 	return CS_OK;
@@ -231,7 +259,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
@@ -312,13 +340,16 @@ __global__ void sort_compact_list_kernel(const OutMem *raw, const uint32_t *cnt2
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)std::max<int64_t>(1, (n + block - 1) / block); }
 
 constexpr int SMEM_BLOCK = 256;
-constexpr int SMEM_LEP_LDS = 20; // 20 x 16 B x 256 lanes = 80 KiB of LDS per workgroup, two workgroups per CU
+// LEP entries kept in LDS per lane: 20 x 16 B x 256 lanes = 80 KiB per workgroup => two workgroups (8 waves) per CU;
+// 10 => 40 KiB => four workgroups (16 waves) per CU, more of the list spilling to global memory.  CS_LEP_LDS selects.
 
 static int launch_smem(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, const uint32_t *d_ids, int64_t n_tasks,
                        OutMem *out, uint32_t *cnt, uint32_t cap, uint32_t max_len)
 {
 	unsigned blocks = (unsigned)std::min<int64_t>((int64_t)e->n_cu * e->blocks_per_cu, (n_tasks + SMEM_BLOCK - 1) / SMEM_BLOCK);
 	if (blocks == 0) return CS_OK;
+	const int SMEM_LEP_LDS = g_lep_lds;
+	blocks = (unsigned)std::min<int64_t>((int64_t)e->n_cu * (SMEM_LEP_LDS <= 10 ? 4 : SMEM_LEP_LDS <= 13 ? 3 : 2), (n_tasks + SMEM_BLOCK - 1) / SMEM_BLOCK);
 	uint32_t spill_cap = max_len + 1 > (uint32_t)SMEM_LEP_LDS ? max_len + 1 - SMEM_LEP_LDS : 1;
 	// long reads: fewer resident workgroups rather than an unbounded spill area (one LEP list per lane, worst case = read length)
 	size_t per_block = (size_t)SMEM_BLOCK * spill_cap * sizeof(uint4);
@@ -334,7 +365,9 @@ static int launch_smem(cs_engine *e, const cs_params_t *par, const uint64_t *d_o
 	A.task_counter = e->d_ctr.p; A.spill = e->d_spill.p; A.spill_cap = spill_cap; A.n_queries = e->d_ctr.p + 1;
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, sizeof(unsigned long long), e->stream));
 	HIP_TRY(hipEventRecord(e->ev[0], e->stream));
-	hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, SMEM_LEP_LDS>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
+	if (SMEM_LEP_LDS == 20) hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 20>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
+	else if (SMEM_LEP_LDS == 13) hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 13>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
+	else hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 10>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[1], e->stream));
 	if (d_ids) e->st.overflow_kernel_launches++; else e->st.seed_kernel_launches++;
@@ -468,8 +501,12 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		if (total_mems)
 			hipLaunchKernelGGL(sal_expand_kernel, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->d_mems.p, total_mems,
 			                   (uint32_t)par->max_occ, som.p, e->d_seeds.p);
-		if (total_seeds)
-			hipLaunchKernelGGL(sal_walk_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
+		if (total_seeds) {
+			if (e->ix.fsa32 || e->ix.fsa64)
+				hipLaunchKernelGGL(sal_gather_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
+			else
+				hipLaunchKernelGGL(sal_walk_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
+		}
 		hipLaunchKernelGGL(seed_off_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, e->d_mem_off.p, som.p, n_reads, e->d_seed_off.p);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(e->ev[1], s));
@@ -577,6 +614,35 @@ extern "C" int cs_engine_sa(cs_engine_t *e, int64_t n, const uint64_t *k, uint64
 	return run_prim<uint64_t, uint64_t>(e, n, k, 1, sa, 1, nullptr, [&](const uint64_t *di, const uint8_t *, uint64_t *dout) {
 		hipLaunchKernelGGL(sa_kernel, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, e->ix, di, dout, n);
 	});
+}
+
+// ------------------------------------------------------------------------------------------------ access-shape micro-benchmark
+// Dependent chains of random 64-byte Occ-block reads, one chain per lane, nothing else: the ceiling of this access shape on
+// the resident index (SURVEY 8d asks for it next to the roofline).  Returns lines per second.
+__global__ void random_block_chain_kernel(const DevIndex ix, uint32_t steps, uint64_t *sink)
+{
+	uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+	for (uint32_t i = 0; i < steps; ++i) {
+		uint64_t b = (k >> 11) % ix.n_blocks;
+		Block blk = load_block(ix, b);
+		k = k * 6364136223846793005ull + (blk.h0.x ^ blk.h1.y ^ blk.w0.z ^ blk.w1.w) + 1442695040888963407ull;
+	}
+	if (k == 42) *sink = k;
+}
+extern "C" int cs_engine_probe_random_lines(cs_engine_t *e, int waves_per_simd, int steps, double *lines_per_sec)
+{
+	if (!e || !lines_per_sec || waves_per_simd < 1 || waves_per_simd > 8 || steps < 1) return fail(CS_EINVAL, "bad argument");
+	HIP_TRY(hipSetDevice(e->device));
+	unsigned blocks = (unsigned)(e->n_cu * waves_per_simd); // 256-thread blocks: 4 waves each => waves_per_simd blocks per CU
+	HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+	hipLaunchKernelGGL(random_block_chain_kernel, dim3(blocks), dim3(256), 0, e->stream, e->ix, (uint32_t)steps, (uint64_t *)e->d_ctr.p + 7);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+	*lines_per_sec = (double)blocks * 256.0 * steps / (ms * 1e-3);
+	return CS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ device memory helpers

@@ -26,6 +26,10 @@ struct DevIndex {
 	uint64_t primary, seq_len, n_sa, n_blocks;
 	uint64_t L2[5];
 	uint32_t sa_mask, sa_shift;
+	// full suffix array materialised in HBM at engine creation (one entry per BWT row, 4 or 8 bytes): SAL becomes ONE
+	// gather instead of a walk of up to sa_intv-1 dependent Occ reads.  Null when disabled / out of memory.
+	const uint32_t *fsa32;
+	const uint64_t *fsa64;
 };
 
 struct Intv { uint64_t x0, x1, x2; };
@@ -163,6 +167,13 @@ __device__ __forceinline__ uint64_t inv_psi(const DevIndex &ix, uint64_t k)
 	uint64_t occ = c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3];
 	uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
 	return l2c + occ;
+}
+
+// bwt_sa through the full suffix array when it is resident (same integers: SA[k] is SA[k] however it is obtained)
+__device__ __forceinline__ uint64_t sa_direct(const DevIndex &ix, uint64_t k)
+{
+	if (k == 0) return ~0ull; // sa[0] = -1 (bwt.c:83)
+	return ix.fsa32 ? (uint64_t)ix.fsa32[k] : ix.fsa64[k];
 }
 
 // bwt_sa (bwt.c:86-96)

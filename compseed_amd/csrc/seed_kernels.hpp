@@ -67,7 +67,7 @@ __device__ __forceinline__ void unpack_lep(const uint4 &e, Intv &v, uint32_t &en
 }
 
 template <int BLOCK, int LEP_LDS>
-__global__ __launch_bounds__(BLOCK, 2) void smem_kernel(const SeedArgs A)
+__global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2)) void smem_kernel(const SeedArgs A)
 {
 	__shared__ uint4 lds_lep[LEP_LDS * BLOCK];
 	const DevIndex &ix = A.ix;
@@ -281,6 +281,32 @@ __global__ void sal_walk_kernel(const DevIndex ix, OutSeed *seeds, uint64_t n_se
 	if (s >= n_seeds) return;
 	seeds[s].rbeg = (int64_t)sa_lookup(ix, (uint64_t)seeds[s].rbeg);
 }
+// the same through the HBM-resident full suffix array: one gather per slot
+__global__ void sal_gather_kernel(const DevIndex ix, OutSeed *seeds, uint64_t n_seeds)
+{
+	uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_seeds) return;
+	seeds[s].rbeg = (int64_t)sa_direct(ix, (uint64_t)seeds[s].rbeg);
+}
+
+// Materialise SA[row] for every row from the 1-in-sa_intv samples: lane t starts at sampled row t*sa_intv, whose value is
+// known, and follows bwt_invPsi (one text position back per step, bwt.c:53-59) writing SA = value - steps until it
+// reaches the next sampled row.  Every row lies on exactly one such chain, so all seq_len+1 rows get written once.
+template <typename T>
+__global__ void sa_fill_kernel(const DevIndex ix, T *full)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ix.n_sa) return;
+	uint64_t k = t << ix.sa_shift;
+	uint64_t s = (t == 0) ? ix.seq_len : ix.sa[t]; // row 0 is the "$" suffix at text position seq_len
+	full[k] = (T)s;
+	for (;;) {
+		k = inv_psi(ix, k);
+		if ((k & ix.sa_mask) == 0) break;
+		--s;
+		full[k] = (T)s;
+	}
+}
 
 __global__ void seed_off_kernel(const uint64_t *mem_off, const uint64_t *seed_of_mem, int64_t n_reads, uint64_t *seed_off)
 {
@@ -315,7 +341,10 @@ __global__ void sa_kernel(const DevIndex ix, const uint64_t *k, uint64_t *sa, in
 {
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n) return;
-	sa[t] = sa_lookup(ix, k[t]);
+	uint64_t walked = sa_lookup(ix, k[t]);
+	// when the full suffix array is resident it must agree with the walk on every row (mismatch => poison the answer)
+	if ((ix.fsa32 || ix.fsa64) && sa_direct(ix, k[t]) != walked) walked = 0xdeadbeefdeadbeefull;
+	sa[t] = walked;
 }
 
 } // namespace csd

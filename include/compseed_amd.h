@@ -135,6 +135,10 @@ int  cs_engine_occ4(cs_engine_t *e, int64_t n, const uint64_t *k, uint64_t *cnt4
 int  cs_engine_extend(cs_engine_t *e, int64_t n, const cs_intv_t *ik, const uint8_t *is_back, cs_intv_t *ok4);
 int  cs_engine_sa(cs_engine_t *e, int64_t n, const uint64_t *k, uint64_t *sa);
 
+/* ---- diagnostic: ceiling of the path's access shape on the resident index -- every lane of `waves_per_simd` x 4 waves
+ *      per CU follows a dependent chain of `steps` random 64-byte Occ-block reads; returns 64-byte lines per second */
+int  cs_engine_probe_random_lines(cs_engine_t *e, int waves_per_simd, int steps, double *lines_per_sec);
+
 /* ---- device memory helpers so that a caller without its own HIP code can stage inputs for the device variant */
 int  cs_device_alloc(cs_engine_t *e, size_t bytes, void **dptr);
 int  cs_device_free(cs_engine_t *e, void *dptr);

@@ -205,7 +205,7 @@ int cso_smem1(const cso_index_t *idx, int len, const uint8_t *q, int x, uint64_t
 		if (q[i] > 3) { lep[n++] = ik; break; }                   /* ambiguous base ends the match */
 		int c = 3 - q[i];
 		int nb = cso_extend(idx, &ik, ok, 0);
-		if (st) { st->bwt_queries++; st->bwt_blocks_uncached += nb; }
+		if (st) { st->bwt_queries++; st->bwt_blocks_uncached += nb; st->q_fwd++; }
 		if (ok[c].x2 != ik.x2) {
 			lep[n++] = ik;
 			if (ok[c].x2 < min_intv) break;
@@ -214,17 +214,20 @@ int cso_smem1(const cso_index_t *idx, int len, const uint8_t *q, int x, uint64_t
 	}
 	if (i == len) lep[n++] = ik;
 	int ret = (int)lep[n - 1].info; /* end of the longest forward match */
+	int hcls = n <= 8 ? 0 : n <= 16 ? 1 : n <= 24 ? 2 : n <= 32 ? 3 : n <= 48 ? 4 : n <= 64 ? 5 : n <= 128 ? 6 : 7;
+	if (st) { st->n_calls++; st->lep_sum += (uint64_t)n; if ((uint64_t)n > st->lep_max) st->lep_max = (uint64_t)n; st->lep_hist[hcls]++; }
 
 	int lo = 0;
 	for (i = x - 1; i >= -1; --i) {
 		int c = (i < 0 || q[i] > 3) ? -1 : q[i];
 		int w = n, kept = 0;
 		uint64_t last_kept = 0;
+		if (st) st->bwd_steps++;
 		for (int j = n - 1; j >= lo; --j) {
 			cso_intv_t p = lep[j];
 			if (c >= 0) {
 				int nb = cso_extend(idx, &p, ok, 1);
-				if (st) { st->bwt_queries++; st->bwt_blocks_uncached += nb; }
+				if (st) { st->bwt_queries++; st->bwt_blocks_uncached += nb; st->q_bwd++; st->q_bwd_hist[hcls]++; }
 			}
 			if (c < 0 || ok[c].x2 < min_intv) {
 				/* cannot grow: an SMEM iff no longer match survived this step and it is not contained */
@@ -259,7 +262,7 @@ int cso_seed_strategy1(const cso_index_t *idx, int len, const uint8_t *q, int x,
 		if (q[i] > 3) return i + 1;
 		int c = 3 - q[i];
 		int nb = cso_extend(idx, &ik, ok, 0);
-		if (st) { st->bwt_queries++; st->bwt_blocks_uncached += nb; }
+		if (st) { st->bwt_queries++; st->bwt_blocks_uncached += nb; st->q_r3++; }
 		if (ok[c].x2 < max_intv && i - x >= min_len) {
 			*mem = ok[c];
 			mem->info = (uint64_t)x << 32 | (uint64_t)(i + 1);
@@ -582,7 +585,9 @@ static void *worker_main(void *arg)
 	if (!J->mode) { w.st.bwt_calls = w.st.bwt_queries; w.st.bwt_blocks = w.st.bwt_blocks_uncached; }
 	pthread_mutex_lock(&J->mu);
 	uint64_t *t = (uint64_t *)&J->total, *s = (uint64_t *)&w.st;
+	uint64_t mx = J->total.lep_max > w.st.lep_max ? J->total.lep_max : w.st.lep_max;
 	for (size_t i = 0; i < sizeof(cso_stats_t) / 8; ++i) t[i] += s[i];
+	J->total.lep_max = mx;
 	pthread_mutex_unlock(&J->mu);
 	free(seq); free(w.lep); free(w.mem); free(w.fwd.a); free(w.bwd.a);
 	return NULL;

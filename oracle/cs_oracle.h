@@ -52,6 +52,13 @@ typedef struct {
 	uint64_t sal_steps;       /* bwt_invPsi steps walked by the distinct slots                                    */
 	uint64_t sal_steps_uncached; /* ... by every requested slot                                                   */
 	uint64_t n_mems, n_seeds;
+	/* workload shape (mode 0 only), used to size the device kernels: */
+	uint64_t q_fwd, q_bwd, q_r3;   /* bwt_extend queries by phase: forward passes of rounds 1-2, backward sweeps, round 3 */
+	uint64_t n_calls;              /* SMEM calls (rounds 1-2)                                                         */
+	uint64_t lep_sum, lep_max;     /* LEP list length at the end of the forward pass                                  */
+	uint64_t bwd_steps;            /* backward positions visited                                                      */
+	uint64_t lep_hist[8];          /* calls with list length <=8, <=16, <=24, <=32, <=48, <=64, <=128, >128            */
+	uint64_t q_bwd_hist[8];        /* backward queries spent in calls of those classes                                */
 } cso_stats_t;
 
 void cso_params_default(cso_params_t *p);

@@ -33,10 +33,12 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("bwt_queries", "bwt_calls", "bwt_blocks", "bwt_blocks_uncached", "sal_queries",
-                                          "sal_calls", "sal_steps", "sal_steps_uncached", "n_mems", "n_seeds")]
+                                          "sal_calls", "sal_steps", "sal_steps_uncached", "n_mems", "n_seeds",
+                                          "q_fwd", "q_bwd", "q_r3", "n_calls", "lep_sum", "lep_max", "bwd_steps")] + \
+               [("lep_hist", C.c_uint64 * 8), ("q_bwd_hist", C.c_uint64 * 8)]
 
     def asdict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.endswith("hist") else int(getattr(self, n))) for n, _ in self._fields_}
 
 
 _lib = None

@@ -124,3 +124,30 @@ def test_matches_oracle_on_fresh_random_reads(eng):
         assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"])
         assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
     o.close()
+
+
+def test_full_sa_agrees_with_walk_everywhere(eng):
+    """every row: the HBM-resident full suffix array == bwt_sa walked from the samples (sa_kernel poisons mismatches)"""
+    n = int(eng._index.view.seq_len)
+    rows = np.arange(0, n + 1, dtype=np.uint64)
+    got = eng.sa(rows)
+    assert not (got == np.uint64(0xdeadbeefdeadbeef)).any()
+    o = _oracle.OracleIndex(_data.PREFIX)
+    pick = np.random.default_rng(1).integers(1, n + 1, 3000)
+    assert [int(got[k]) for k in pick] == [o.sa(int(k)) for k in pick]
+    o.close()
+
+
+def test_sampled_sa_walk_path(monkeypatch):
+    """CS_FULL_SA=0: SAL walks bwt_invPsi from the 1-in-32 samples like the reference (bwt.c:86-96); same seeds"""
+    import compseed_amd as ca
+    monkeypatch.setenv("CS_FULL_SA", "0")
+    monkeypatch.setenv("CS_MEM_CAP", "8")   # also force most reads through the overflow second pass
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0)
+    for name, pname in (("repeat100", "default"), ("ragged", "k14"), ("main100", "c50s20")):
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+    assert e.stats()["overflow_reads"] > 0
+    e.close(); ix.close()

@@ -14,6 +14,9 @@ ASCII = torch.tensor([65, 67, 71, 84], dtype=torch.uint8)  # ACGT
 
 def make_genome(length, seed=1, device="cuda", alu_frac=0.10, alu_div=0.12, n_segdup=None, n_tandem=None):
     """uint8 codes 0..3 on `device`"""
+    import os
+    if os.environ.get("CS_SYNTH_NO_TANDEM"):
+        n_tandem = 0
     g = torch.Generator(device=device); g.manual_seed(seed)
     G = torch.randint(0, 4, (length,), dtype=torch.uint8, device=device, generator=g)
     # interspersed family: 300-bp consensus, copies diverged by alu_div substitutions
@@ -42,7 +45,7 @@ def make_genome(length, seed=1, device="cuda", alu_frac=0.10, alu_div=0.12, n_se
             G[b:b + 5000] = seg
     # tandem arrays: 17..60-bp unit x 100..600 copies
     n_tandem = max(2, length // 5_000_000) if n_tandem is None else n_tandem
-    if length > 100_000:
+    if length > 100_000 and n_tandem > 0:
         for _ in range(n_tandem):
             ul = int(torch.randint(17, 61, (1,), device=device, generator=g)); cn = int(torch.randint(100, 601, (1,), device=device, generator=g))
             p = int(torch.randint(0, length - ul * cn, (1,), device=device, generator=g))
