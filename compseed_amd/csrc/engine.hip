@@ -4,6 +4,7 @@
 // and SAL blocks only.  No CPU fallback exists: without a HIP device every entry point fails with CS_EDEVICE.
 #include "cs_internal.hpp"
 #include "seed_kernels.hpp"
+#include "smem_split.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -14,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 using namespace csd;
@@ -98,6 +100,12 @@ struct cs_engine {
 	// results (pinned host)
 	PinBuf<uint64_t> h_mem_off, h_seed_off; PinBuf<OutMem> h_mems; PinBuf<OutSeed> h_seeds;
 	PinBuf<unsigned long long> h_ctr;
+	// split (forward / cooperative backward) SMEM path
+	DevBuf<uint64_t> d_fqA, d_fqB; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
+	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
+	int smem_mode = 1;          // 1 = split kernels (default), 0 = fused one-lane-per-read kernel (CS_SMEM_MODE=fused)
+	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
+	size_t lep_arena_bytes = (size_t)12 << 30;
 	cs_stats_t st{};
 	uint32_t cap = 64;          // mems per read kept by the first pass
 	size_t max_raw_bytes = (size_t)24 << 30;
@@ -199,6 +207,19 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	HIP_TRY(hipMemcpyAsync(e->d_bwt.p, v->bwt, (size_t)v->bwt_size * 4, hipMemcpyHostToDevice, e->stream));
 	CS_TRY(e->d_sa.reserve((size_t)v->n_sa));
 	HIP_TRY(hipMemcpyAsync(e->d_sa.p, v->sa, (size_t)v->n_sa * 8, hipMemcpyHostToDevice, e->stream));
+	// one-time conversion of the 2-bit packed bases of every block into bit planes (fm_device.hpp)
+	hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, e->stream, e->d_bwt.p, n_blocks);
+	HIP_TRY(hipGetLastError());
+	CS_TRY(e->d_sctr.reserve(16));
+	CS_TRY(e->h_sctr.reserve(16));
+	{
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fwd_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_fwd = std::min(nb, 8);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_kernel<256, 16>, 256, 0) == hipSuccess && nb > 0) e->occ_bwd = std::min(nb, 8);
+		(void)hipGetLastError();
+	}
+	if (const char *m = getenv("CS_SMEM_MODE")) e->smem_mode = strcmp(m, "fused") == 0 ? 0 : 1;
+	if (const char *m = getenv("CS_LEP_ARENA_MB")) { long v = atol(m); if (v >= 1) e->lep_arena_bytes = (size_t)v << 20; }
 	CS_TRY(e->d_ctr.reserve(8));
 	CS_TRY(e->h_ctr.reserve(8));
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 8 * sizeof(unsigned long long), e->stream));
@@ -263,6 +284,8 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
+	e->d_fqA.release(); e->d_fqB.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
+	e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -382,6 +405,88 @@ static int add_event_ms(cs_engine *e, hipEvent_t a, hipEvent_t b, double *acc)
 	return CS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ split SMEM path
+// Runs the three rounds for reads [0, nb) of d_off with fwd_kernel / bwd_kernel (smem_split.hpp).  On return d_cnt holds
+// the number of mems per read, d_out the first `cap` of each, d_ovfrec/*n_ovf the rest.  Returns 1 when a task queue
+// overflowed (the caller then falls back to the fused kernel for this sub-batch).
+static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, int64_t nb, uint32_t max_len, uint64_t *n_ovf_out)
+{
+	hipStream_t s = e->stream;
+	*n_ovf_out = 0;
+	if (par->split_width > 16382) return 1; // min_intv does not fit the 14-bit task field: use the fused kernel
+	const uint32_t stride = max_len + 1;
+	const uint64_t fq_cap = (uint64_t)nb * 8 + 4096, ovf_cap = (uint64_t)nb * 4 + 65536;
+	uint64_t chunk = std::max<uint64_t>(4096, e->lep_arena_bytes / ((size_t)stride * sizeof(uint4)));
+	chunk = std::min<uint64_t>(chunk, fq_cap);
+	CS_TRY(e->d_fqA.reserve(fq_cap)); CS_TRY(e->d_fqB.reserve(fq_cap));
+	CS_TRY(e->d_bq.reserve(4 * chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
+	CS_TRY(e->d_ovfrec.reserve(ovf_cap));
+	unsigned long long *C = e->d_sctr.p, *H = e->h_sctr.p; // [0] task ctr [1] next-queue length [2..5] backward queues [6] overflow mems [7] error [8] queries
+	HIP_TRY(hipMemsetAsync(C, 0, 16 * sizeof(unsigned long long), s));
+	HIP_TRY(hipMemsetAsync(e->d_cnt.p, 0, ((size_t)nb + 1) * sizeof(uint32_t), s));
+
+	SplitArgs A;
+	A.ix = e->ix; A.seq = e->d_seq.p; A.off = d_off; A.n_reads = nb;
+	A.out = e->d_out.p; A.out_cnt = e->d_cnt.p; A.cap = e->cap;
+	A.ovf = e->d_ovfrec.p; A.ovf_cnt = C + 6; A.ovf_cap = ovf_cap;
+	A.min_seed_len = par->min_seed_len;
+	A.split_len = (int)(1.0 * par->min_seed_len * par->split_factor + .499); // comp_seed.cpp:2279 (double arithmetic)
+	A.split_width = (uint32_t)par->split_width; A.max_mem_intv = par->max_mem_intv;
+	A.bq = e->d_bq.p; A.n_b = C + 2; A.bq_cap = chunk;
+	A.lep = e->d_lep.p; A.lep_stride = stride;
+	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7;
+	A.fq_cap = fq_cap; A.n_f_next = C + 1;
+
+	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;
+	A.fq = cur; A.n_f = 0; A.fq_next = nxt;
+	HIP_TRY(hipEventRecord(e->ev[0], s));
+	hipLaunchKernelGGL(init_tasks_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, A, cur);
+	uint64_t n_f = 2 * (uint64_t)nb;
+	for (int iter = 0; n_f > 0; ++iter) {
+		A.fq_next = nxt;
+		for (uint64_t c0 = 0; c0 < n_f; c0 += chunk) {
+			uint64_t cn = std::min<uint64_t>(chunk, n_f - c0);
+			A.fq = cur + c0; A.n_f = cn;
+			HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+			HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
+			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
+			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			if (H[7]) return 1;
+			for (int cls = 0; cls < 4; ++cls) {
+				uint64_t nbt = H[2 + cls];
+				if (!nbt) continue;
+				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+				const BTask *q = e->d_bq.p + (size_t)cls * chunk;
+				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
+				if (cls == 0)      hipLaunchKernelGGL((bwd_kernel<256, 16>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 15) / 16)), dim3(256), 0, s, A, q, nbt);
+				else if (cls == 1) hipLaunchKernelGGL((bwd_kernel<256, 32>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 7) / 8)), dim3(256), 0, s, A, q, nbt);
+				else if (cls == 2) hipLaunchKernelGGL((bwd_kernel<256, 64>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 3) / 4)), dim3(256), 0, s, A, q, nbt);
+				else               hipLaunchKernelGGL(bwd_serial_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 63) / 64)), dim3(64), 0, s, A, q, nbt);
+				HIP_TRY(hipGetLastError());
+			}
+		}
+		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (H[7]) return 1;
+		n_f = H[1];
+		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
+		std::swap(cur, nxt);
+		if (iter > 70000) return fail(CS_EDEVICE, "SMEM task chain did not terminate");
+	}
+	HIP_TRY(hipEventRecord(e->ev[1], s));
+	HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
+	e->st.seed_kernel_launches++;
+	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8];
+	*n_ovf_out = H[6];
+	return CS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ the hot path
 static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
                             uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out)
@@ -425,6 +530,33 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	uint64_t total_mems = 0;
 	for (int64_t b0 = 0; b0 < n_reads; b0 += per_launch) {
 		int64_t nb = std::min<int64_t>(per_launch, n_reads - b0);
+		if (e->smem_mode == 1) {
+			uint64_t n_ovf2 = 0;
+			int rc = run_smem_split(e, par, d_off + b0, nb, max_len, &n_ovf2);
+			if (rc < 0) return rc;
+			if (rc == 0) {
+				if (n_ovf2) { // the few mems beyond a read's first `cap`: sort their records by read id
+					e->st.overflow_reads += n_ovf2;
+					CS_TRY(e->d_okey.reserve(n_ovf2)); CS_TRY(e->d_oidx.reserve(n_ovf2)); CS_TRY(e->d_okey2.reserve(n_ovf2)); CS_TRY(e->d_oidx2.reserve(n_ovf2));
+					hipLaunchKernelGGL(ovf_keys_kernel, dim3(grid_for((int64_t)n_ovf2, 256)), dim3(256), 0, s, e->d_ovfrec.p, n_ovf2, e->d_okey.p, e->d_oidx.p);
+					size_t tb = 0;
+					HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, e->d_okey.p, e->d_okey2.p, e->d_oidx.p, e->d_oidx2.p, (size_t)n_ovf2, 0u, 32u, s));
+					CS_TRY(e->d_tmp2.reserve(tb + 16));
+					HIP_TRY(rocprim::radix_sort_pairs((void *)e->d_tmp2.p, tb, e->d_okey.p, e->d_okey2.p, e->d_oidx.p, e->d_oidx2.p, (size_t)n_ovf2, 0u, 32u, s));
+				}
+				CS_TRY(scan_counts(e, e->d_cnt.p, e->d_mem_off.p + b0, (size_t)nb, total_mems));
+				HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_mem_off.p + b0 + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+				HIP_TRY(hipStreamSynchronize(s));
+				uint64_t new_total = e->h_ctr.p[0];
+				CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
+				hipLaunchKernelGGL(sort_compact2_kernel, dim3(grid_for(nb, 128)), dim3(128), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
+				                   e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p);
+				HIP_TRY(hipGetLastError());
+				total_mems = new_total;
+				continue;
+			}
+			// rc == 1: a task queue overflowed -- redo this sub-batch with the fused kernel
+		}
 		HIP_TRY(hipMemsetAsync(e->d_cnt.p + nb, 0, sizeof(uint32_t), s));
 		CS_TRY(launch_smem(e, par, d_off + b0, nullptr, nb, e->d_out.p, e->d_cnt.p, cap, max_len));
 		HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, sizeof(unsigned long long), s));
@@ -625,7 +757,7 @@ __global__ void random_block_chain_kernel(const DevIndex ix, uint32_t steps, uin
 	for (uint32_t i = 0; i < steps; ++i) {
 		uint64_t b = (k >> 11) % ix.n_blocks;
 		Block blk = load_block(ix, b);
-		k = k * 6364136223846793005ull + (blk.h0.x ^ blk.h1.y ^ blk.w0.z ^ blk.w1.w) + 1442695040888963407ull;
+		k = k * 6364136223846793005ull + (blk.h0.x ^ blk.h1.y ^ blk.lo.z ^ blk.hi.w) + 1442695040888963407ull;
 	}
 	if (k == 42) *sink = k;
 }

@@ -3,15 +3,17 @@
 // Replaces (integer-exact) the reference's bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_set_intv / bwt_occ /
 // bwt_invPsi / bwt_sa (FM_index/bwt.c:169-186, 189-220, 262-275, 107-129, 53-59, 86-96; bwt.h:82).
 //
-// Layout (unchanged from <prefix>.bwt, FM_index/bwt.h:73-80): block b covers BWT rows 128b .. 128b+127
-// ($ removed) and is 64 bytes = 4 x 16-byte quads:
-//     quad 0: count(A), count(C)   (u64 each, occurrences before the block)
-//     quad 1: count(G), count(T)
-//     quad 2: bases   0..63        (4 words, base j of a word in bits (15-j)*2, i.e. first base in the top bits)
-//     quad 3: bases  64..127
-// One lane owns one query, so a block is four global_load_dwordx4 of one 64-byte line.  The reference counts with a
-// 256-entry byte LUT (bwt.c:42-51,165); here each word is reduced with 2-bit lane compares and v_bcnt_u32_b32
-// (popcount-accumulate), A being derived from the number of bases taken -- same integers, no table, no LDS.
+// Device layout of the Occ-sampled BWT.  The file layout (FM_index/bwt.h:73-80) is kept block for block -- block b
+// covers BWT rows 128b .. 128b+127 ($ removed) and is ONE 64-byte line -- but inside the line the 128 two-bit bases
+// are stored as two bit planes instead of sixteen packed bases per word (relayout_kernel converts once at upload):
+//     quad 0: count(A), count(C)   (u64 each, occurrences before the block)          unchanged
+//     quad 1: count(G), count(T)                                                      unchanged
+//     quad 2: low  bit of bases 0..127  (word w, bit j = base 32w + j)
+//     quad 3: high bit of bases 0..127
+// One lane owns one query, so a block is four global_load_dwordx4 of one line.  Counting the bases up to a row is then
+// 4 words x (3 logic + 3 masked v_bcnt_u32_b32) with a simple "first t bits" mask per word, about half the vector
+// instructions of counting in the packed format and no 256-entry LUT (bwt.c:42-51,165) -- the kernels are bound by
+// instruction issue as much as by HBM latency, so this matters.  A is derived from the number of bases taken.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,7 +23,7 @@ namespace csd {
 constexpr uint64_t NONE64 = ~0ull;
 
 struct DevIndex {
-	const uint4    *bwt;      // 64-byte blocks as 4 quads
+	const uint4    *bwt;      // 64-byte blocks as 4 quads (bit-plane layout above)
 	const uint64_t *sa;       // sampled SA, sa[0] = -1
 	uint64_t primary, seq_len, n_sa, n_blocks;
 	uint64_t L2[5];
@@ -36,39 +38,54 @@ struct Intv { uint64_t x0, x1, x2; };
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
 
-// occurrences of C, G, T among the first `nb` (0..128) bases of a block's 8 words
-__device__ __forceinline__ void count_cgt(const uint4 &qa, const uint4 &qb, uint32_t nb, uint32_t &c1, uint32_t &c2, uint32_t &c3)
+// file layout -> bit planes, in place, one thread per block (run once per engine)
+__global__ void relayout_kernel(uint4 *bwt, uint64_t n_blocks)
 {
-	const uint32_t w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-	c1 = c2 = c3 = 0;
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		int rem = (int)nb - 16 * i;                    // bases wanted from this word
-		rem = rem < 0 ? 0 : (rem > 16 ? 16 : rem);
-		// low bit of every wanted 2-bit lane: the (16-rem) trailing lanes are cut off
-		uint32_t m = (uint32_t)(0x55555555ull << ((16 - rem) << 1)) & 0x55555555u;
-		uint32_t lo = w[i], hi = w[i] >> 1;
-		c1 += __builtin_popcount(lo & ~hi & m);        // 01
-		c2 += __builtin_popcount(hi & ~lo & m);        // 10
-		c3 += __builtin_popcount(lo & hi & m);         // 11
+	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks) return;
+	uint4 q2 = bwt[b * 4 + 2], q3 = bwt[b * 4 + 3];
+	const uint32_t w[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+	uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+	for (int i = 0; i < 128; ++i) {
+		uint32_t code = (w[i >> 4] >> ((15 - (i & 15)) << 1)) & 3u; // bwt_B0, bwt.h:80
+		lo[i >> 5] |= (code & 1u) << (i & 31);
+		hi[i >> 5] |= (code >> 1) << (i & 31);
 	}
+	bwt[b * 4 + 2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+	bwt[b * 4 + 3] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
-struct Block { uint4 h0, h1, w0, w1; };
+struct Block { uint4 h0, h1, lo, hi; };
 
 __device__ __forceinline__ Block load_block(const DevIndex &ix, uint64_t b)
 {
 	const uint4 *p = ix.bwt + (b << 2);
 	Block k;
-	k.h0 = p[0]; k.h1 = p[1]; k.w0 = p[2]; k.w1 = p[3];
+	k.h0 = p[0]; k.h1 = p[1]; k.lo = p[2]; k.hi = p[3];
 	return k;
+}
+
+// occurrences of C, G, T among the first `nb` (1..128) bases of a block
+__device__ __forceinline__ void count_cgt(const Block &k, uint32_t nb, uint32_t &c1, uint32_t &c2, uint32_t &c3)
+{
+	const uint32_t L[4] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w}, H[4] = {k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+	c1 = c2 = c3 = 0;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		int t = (int)nb - 32 * w;                                 // bases wanted from this word
+		uint32_t m = t >= 32 ? 0xffffffffu : (t <= 0 ? 0u : ((1u << t) - 1u));
+		uint32_t lo = L[w] & m, hi = H[w] & m;
+		c1 += __builtin_popcount(lo & ~hi);                       // 01 = C
+		c2 += __builtin_popcount(hi & ~lo);                       // 10 = G
+		c3 += __builtin_popcount(lo & hi);                        // 11 = T
+	}
 }
 
 // counts of A,C,G,T in rows [0, row] given the block that holds `row` (row already primary-adjusted)
 __device__ __forceinline__ void occ4_in_block(const Block &k, uint64_t row, uint64_t cnt[4])
 {
 	uint32_t nb = (uint32_t)(row & 127) + 1, c1, c2, c3;
-	count_cgt(k.w0, k.w1, nb, c1, c2, c3);
+	count_cgt(k, nb, c1, c2, c3);
 	cnt[0] = u64_of(k.h0.x, k.h0.y) + (nb - c1 - c2 - c3);
 	cnt[1] = u64_of(k.h0.z, k.h0.w) + c1;
 	cnt[2] = u64_of(k.h1.x, k.h1.y) + c2;
@@ -102,13 +119,18 @@ __device__ __forceinline__ int occ2x4(const DevIndex &ix, uint64_t k, uint64_t l
 	return (kn && ln) ? 0 : ((kn || ln) ? 1 : ((rk >> 7) != (rl >> 7) ? 2 : 1));
 }
 
+__device__ __forceinline__ uint64_t sel4(int c, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3)
+{
+	return c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
+}
+
 // bwt_set_intv (bwt.h:82)
 __device__ __forceinline__ Intv set_intv(const DevIndex &ix, int c)
 {
 	Intv v;
-	uint64_t lc  = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
-	uint64_t lc1 = c == 0 ? ix.L2[1] : c == 1 ? ix.L2[2] : c == 2 ? ix.L2[3] : ix.L2[4];
-	uint64_t lr  = c == 0 ? ix.L2[3] : c == 1 ? ix.L2[2] : c == 2 ? ix.L2[1] : ix.L2[0];
+	uint64_t lc  = sel4(c, ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3]);
+	uint64_t lc1 = sel4(c, ix.L2[1], ix.L2[2], ix.L2[3], ix.L2[4]);
+	uint64_t lr  = sel4(c, ix.L2[3], ix.L2[2], ix.L2[1], ix.L2[0]);
 	v.x0 = lc + 1; v.x2 = lc1 - lc; v.x1 = lr + 1;
 	return v;
 }
@@ -131,23 +153,47 @@ __device__ __forceinline__ int extend4(const DevIndex &ix, const Intv &ik, bool 
 	return lines;
 }
 
-// bwt_extend restricted to the one child the SMEM search uses: child `c` (0..3) of ik in direction is_back
-// (forward extension by read base q uses c = 3 - q, bwt.c:309-315; backward uses c = q, bwt.c:327).
-__device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, bool is_back, int c)
+// bwt_extend restricted to the one child the SMEM search uses: child `c` (0..3) of ik in direction IS_BACK
+// (forward extension by read base q uses c = 3 - q, bwt.c:309-315; backward uses c = q, bwt.c:327).  Both rows of the
+// searched coordinate are primary-adjusted and fetched before anything is counted, so the two lines travel together.
+// The searched coordinate is never 0 for a real bi-interval (it starts at L2[c]+1 >= 1), so the k == -1 sentinel of
+// bwt_2occ4 cannot occur here; the four-child form above keeps it for the primitive-level entry points.
+template <bool IS_BACK>
+__device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int c)
 {
-	uint64_t xa = is_back ? ik.x0 : ik.x1, xb = is_back ? ik.x1 : ik.x0;
-	uint64_t tk[4], tl[4];
-	occ2x4(ix, xa - 1, xa - 1 + ik.x2, tk, tl);
-	uint64_t s1 = tl[1] - tk[1], s2 = tl[2] - tk[2], s3 = tl[3] - tk[3], s0 = tl[0] - tk[0];
-	uint64_t tkc = c == 0 ? tk[0] : c == 1 ? tk[1] : c == 2 ? tk[2] : tk[3];
-	uint64_t sc  = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
-	uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
+	uint64_t xa = IS_BACK ? ik.x0 : ik.x1, xb = IS_BACK ? ik.x1 : ik.x0;
+	uint64_t k = xa - 1, l = xa - 1 + ik.x2;
+	uint64_t rk = k - (k >= ix.primary), rl = l - (l >= ix.primary);
+	Block bk = load_block(ix, rk >> 7);
+	Block bl = load_block(ix, rl >> 7);
+	uint32_t nk = (uint32_t)(rk & 127) + 1, nl = (uint32_t)(rl & 127) + 1, k1, k2, k3, l1, l2, l3;
+	count_cgt(bk, nk, k1, k2, k3);
+	count_cgt(bl, nl, l1, l2, l3);
+	uint64_t tk0 = u64_of(bk.h0.x, bk.h0.y) + (nk - k1 - k2 - k3), tl0 = u64_of(bl.h0.x, bl.h0.y) + (nl - l1 - l2 - l3);
+	uint64_t tk1 = u64_of(bk.h0.z, bk.h0.w) + k1, tl1 = u64_of(bl.h0.z, bl.h0.w) + l1;
+	uint64_t tk2 = u64_of(bk.h1.x, bk.h1.y) + k2, tl2 = u64_of(bl.h1.x, bl.h1.y) + l2;
+	uint64_t tk3 = u64_of(bk.h1.z, bk.h1.w) + k3, tl3 = u64_of(bl.h1.z, bl.h1.w) + l3;
+	uint64_t s0 = tl0 - tk0, s1 = tl1 - tk1, s2 = tl2 - tk2, s3 = tl3 - tk3;
+	uint64_t tkc = sel4(c, tk0, tk1, tk2, tk3);
+	uint64_t sc  = sel4(c, s0, s1, s2, s3);
+	uint64_t l2c = sel4(c, ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3]);
 	// children of larger bases sit in front of child c on the shifted coordinate (cascade of bwt.c:271-274)
 	uint64_t above = (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
 	uint64_t ya = l2c + 1 + tkc;
 	uint64_t yb = xb + ((xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) ? 1 : 0) + above;
 	Intv o;
-	o.x0 = is_back ? ya : yb; o.x1 = is_back ? yb : ya; o.x2 = sc;
+	o.x0 = IS_BACK ? ya : yb; o.x1 = IS_BACK ? yb : ya; o.x2 = sc;
+	return o;
+}
+
+// direction chosen at run time (the fused single-kernel path): forward extension is backward extension with the two
+// coordinates swapped (bwt.c:265-274 is symmetric in x[!is_back] / x[is_back])
+__device__ __forceinline__ Intv extend1_rt(const DevIndex &ix, const Intv &ik, bool is_back, int c)
+{
+	Intv s;
+	s.x0 = is_back ? ik.x0 : ik.x1; s.x1 = is_back ? ik.x1 : ik.x0; s.x2 = ik.x2;
+	Intv y = extend1<true>(ix, s, c), o;
+	o.x0 = is_back ? y.x0 : y.x1; o.x1 = is_back ? y.x1 : y.x0; o.x2 = y.x2;
 	return o;
 }
 
@@ -157,16 +203,13 @@ __device__ __forceinline__ uint64_t inv_psi(const DevIndex &ix, uint64_t k)
 	if (k == ix.primary) return 0;
 	uint64_t row = k - (k > ix.primary);
 	Block b = load_block(ix, row >> 7);
-	uint32_t p = (uint32_t)(row & 127);
-	uint32_t wsel = p >> 4;
-	uint32_t word = wsel == 0 ? b.w0.x : wsel == 1 ? b.w0.y : wsel == 2 ? b.w0.z : wsel == 3 ? b.w0.w
-	              : wsel == 4 ? b.w1.x : wsel == 5 ? b.w1.y : wsel == 6 ? b.w1.z : b.w1.w;
-	int c = (word >> ((~p & 15) << 1)) & 3;
+	uint32_t p = (uint32_t)(row & 127), w = p >> 5, bit = p & 31;
+	uint32_t lo = w == 0 ? b.lo.x : w == 1 ? b.lo.y : w == 2 ? b.lo.z : b.lo.w;
+	uint32_t hi = w == 0 ? b.hi.x : w == 1 ? b.hi.y : w == 2 ? b.hi.z : b.hi.w;
+	int c = (int)(((lo >> bit) & 1u) | (((hi >> bit) & 1u) << 1));
 	uint64_t cnt[4];
 	occ4_in_block(b, row, cnt);
-	uint64_t occ = c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3];
-	uint64_t l2c = c == 0 ? ix.L2[0] : c == 1 ? ix.L2[1] : c == 2 ? ix.L2[2] : ix.L2[3];
-	return l2c + occ;
+	return sel4(c, ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3]) + sel4(c, cnt[0], cnt[1], cnt[2], cnt[3]);
 }
 
 // bwt_sa through the full suffix array when it is resident (same integers: SA[k] is SA[k] however it is obtained)

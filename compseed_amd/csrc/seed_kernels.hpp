@@ -187,7 +187,7 @@ __global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2))
 
 		// ---------------------------------------------------------------- the one extension site
 		Intv src = is_back ? pj : ik;
-		Intv y = extend1(ix, src, is_back, c);
+		Intv y = extend1_rt(ix, src, is_back, c);
 		++my_queries;
 
 		// ---------------------------------------------------------------- consume
@@ -332,8 +332,10 @@ __global__ void extend_kernel(const DevIndex ix, const OutMem *ik, const uint8_t
 	for (int c = 0; c < 4; ++c) {
 		OutMem m = {o[c].x0, o[c].x1, o[c].x2, 0};
 		ok[4 * t + c] = m;
-		// the single-child path used by the search must agree with the four-child one
-		Intv o1 = extend1(ix, v, is_back[t] != 0, c);
+		// the single-child paths used by the search must agree with the four-child one
+		Intv o1 = extend1_rt(ix, v, is_back[t] != 0, c);
+		Intv o2 = is_back[t] ? extend1<true>(ix, v, c) : extend1<false>(ix, v, c);
+		if (v.x0 != 0 && v.x1 != 0 && (o2.x0 != o[c].x0 || o2.x1 != o[c].x1 || o2.x2 != o[c].x2)) ok[4 * t + c].info = 2;
 		if (o1.x0 != o[c].x0 || o1.x1 != o[c].x1 || o1.x2 != o[c].x2) ok[4 * t + c].info = 1;
 	}
 }

@@ -1,0 +1,335 @@
+// smem_split.hpp -- the SMEM collection as a forward kernel and wavefront-cooperative backward kernels (gfx950).
+//
+// Same result as smem_kernel (seed_kernels.hpp) and as the reference's three rounds (mapping/bwamem.c:218-272 ==
+// mapping/comp_seed.cpp:2262-2301), organised around what the hardware is good at.  Measured on MI355X the fused
+// one-lane-per-read state machine is bound by instruction issue and by the one-chain-per-lane latency, not by HBM
+// (a bare dependent chain of random 64-byte reads runs at 57 G lines/s, 3.6 TB/s; the fused kernel reached 35 % of
+// that), and 54 % of all bwt_extend calls belong to backward sweeps that extend ~9 independent intervals per step.
+//
+//   fwd_kernel   one LANE per task.  A task is the forward pass of one SMEM call (bwt.c:300-320) or the whole round-3
+//                chain of a read (bwt_seed_strategy1, bwt.c:358-379).  The loop body is one forward bwt_extend plus a
+//                compare; LEPs (intervals where the occurrence count changes) are streamed to a per-task list in HBM
+//                with fire-and-forget 16-byte stores.  No LDS, so occupancy is set by registers only.
+//   bwd_kernel   a GROUP of G lanes (16/32/64) per SMEM call.  Lane g holds LEP n-1-g in registers; every step of the
+//                backward sweep (bwt.c:325-345) extends ALL live intervals at once -- one memory round trip per read
+//                position instead of one per interval -- and the reference's sequential keep/emit rules are evaluated
+//                with a ballot and one shuffle: occurrence counts are monotone along the list (a longer match cannot
+//                occur more often), so the intervals that stop form a prefix, only the first of them can be a new
+//                SMEM, and "differs from the last kept size" is a comparison with the previous surviving lane.
+//   bwd_serial_kernel  the same sweep by one lane over the list in HBM, for the rare call with more than 64 LEPs.
+//
+// Calls are chained through task queues in HBM: a finished backward sweep of round 1 enqueues the forward pass at the
+// next pivot (bwamem.c:226-236), and every emitted round-1 SMEM that is long and rare enough enqueues its re-seeding
+// call (bwamem.c:241-249) -- those depend only on that one SMEM, so all of them run in parallel.  The host alternates
+// fwd / bwd launches until the queues are empty.  Mems of a read are appended with one atomic per mem and sorted
+// afterwards (comp_seed.cpp:2301), so the order in which tasks finish is irrelevant to the output.
+#pragma once
+#include "fm_device.hpp"
+#include "seed_kernels.hpp"
+
+namespace csd {
+
+enum : uint32_t { TK_ROUND1 = 0, TK_ROUND2 = 1, TK_ROUND3 = 2, TK_NOP = 3 };
+
+// forward task, 8 bytes: read | pivot | min_intv | kind
+__device__ __host__ __forceinline__ uint64_t ftask_pack(uint32_t r, uint32_t x, uint32_t min_intv, uint32_t kind)
+{
+	return (uint64_t)r | (uint64_t)x << 32 | (uint64_t)min_intv << 48 | (uint64_t)kind << 62;
+}
+
+struct BTask { uint32_t r; uint16_t x, mi_kind, n, ret; uint32_t slot; }; // 16 bytes; slot = index of the LEP list
+struct OvfRec { OutMem m; uint32_t r, pad; };                              // a mem beyond a read's first `cap`
+
+struct SplitArgs {
+	DevIndex ix;
+	const uint8_t  *seq;
+	const uint64_t *off;
+	int64_t   n_reads;
+	OutMem   *out; uint32_t *out_cnt; uint32_t cap;
+	OvfRec   *ovf; unsigned long long *ovf_cnt; uint64_t ovf_cap;
+	int32_t   min_seed_len, split_len;
+	uint32_t  split_width;
+	uint64_t  max_mem_intv;
+	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
+	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
+	BTask    *bq; unsigned long long *n_b; uint64_t bq_cap;   // 4 classes: bq + c*bq_cap, n_b[c]
+	uint4    *lep; uint32_t lep_stride;               // LEP list of forward task t: lep + t*lep_stride
+	unsigned long long *task_ctr;
+	unsigned long long *n_queries;
+	unsigned long long *err;                          // sticky: a queue overflowed
+};
+
+__device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const Intv &v, uint32_t beg, uint32_t end)
+{
+	OutMem m = {v.x0, v.x1, v.x2, (uint64_t)beg << 32 | end};
+	uint32_t k = atomicAdd(&A.out_cnt[r], 1u);
+	if (k < A.cap) A.out[(size_t)r * A.cap + k] = m;
+	else {
+		unsigned long long s = atomicAdd(A.ovf_cnt, 1ull);
+		if (s < A.ovf_cap) { OvfRec o = {m, r, 0}; A.ovf[s] = o; } else atomicMax(A.err, 1ull);
+	}
+}
+__device__ __forceinline__ void push_ftask(const SplitArgs &A, uint64_t t)
+{
+	unsigned long long s = atomicAdd(A.n_f_next, 1ull);
+	if (s < A.fq_cap) A.fq_next[s] = t; else atomicMax(A.err, 2ull);
+}
+// an SMEM of a round-1/2 call: length filter (bwamem.c:232,246), and for round 1 the re-seeding call it triggers
+__device__ __forceinline__ void emit_smem(const SplitArgs &A, uint32_t r, uint32_t kind, const Intv &v, int beg, uint32_t end)
+{
+	int len = (int)end - beg;
+	if (len < A.min_seed_len) return;
+	emit_mem(A, r, v, (uint32_t)beg, end);
+	if (kind == TK_ROUND1 && len >= A.split_len && v.x2 <= A.split_width)
+		push_ftask(A, ftask_pack(r, (uint32_t)(beg + (int)end) >> 1, (uint32_t)v.x2 + 1, TK_ROUND2));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// initial tasks: round-1 call at the first unambiguous base, and the round-3 chain (bwamem.c:226, 253)
+__global__ void init_tasks_kernel(const SplitArgs A, uint64_t *fq)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= A.n_reads) return;
+	uint64_t b = A.off[r]; int len = (int)(A.off[r + 1] - b), x = 0;
+	while (x < len && A.seq[b + x] > 3) ++x;
+	fq[2 * r] = x < len ? ftask_pack((uint32_t)r, (uint32_t)x, 1, TK_ROUND1) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+	fq[2 * r + 1] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+}
+
+// sequential reader of a read's bases: 8-base window in a register, the next window prefetched when one is entered
+template <int DIR> struct BaseReader {
+	const uint8_t *seq; uint64_t rbase; uint64_t cur, nxt; uint64_t wk;
+	__device__ __forceinline__ void start(const uint8_t *s, uint64_t rb, int pos)
+	{
+		seq = s; rbase = rb;
+		uint64_t a = rb + (uint64_t)(pos < 0 ? 0 : pos);
+		wk = a >> 3;
+		cur = *reinterpret_cast<const uint64_t *>(seq + (wk << 3));
+		uint64_t nk = DIR > 0 ? wk + 1 : (wk ? wk - 1 : 0);
+		nxt = *reinterpret_cast<const uint64_t *>(seq + (nk << 3));
+	}
+	__device__ __forceinline__ uint32_t at(int pos)
+	{
+		uint64_t a = rbase + (uint64_t)pos, k = a >> 3;
+		if (k != wk) { // moved on by one window in direction DIR
+			cur = nxt; wk = k;
+			uint64_t nk = DIR > 0 ? k + 1 : (k ? k - 1 : 0);
+			nxt = *reinterpret_cast<const uint64_t *>(seq + (nk << 3));
+		}
+		return (uint32_t)(cur >> ((a & 7) << 3)) & 0xffu;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
+{
+	const DevIndex &ix = A.ix;
+	bool active = false;
+	uint64_t tslot = 0; uint32_t r = 0, kind = 0, min_intv = 1;
+	int len = 0, x = 0, i = 0, n = 0;
+	Intv ik = {0, 0, 0};
+	BaseReader<1> rd;
+	uint4 *lep = nullptr;
+	unsigned long long my_q = 0;
+
+	for (;;) {
+		if (!active) {
+			tslot = atomicAdd(A.task_ctr, 1ull);
+			if (tslot >= A.n_f) break;
+			uint64_t t = A.fq[tslot];
+			kind = (uint32_t)(t >> 62);
+			if (kind == TK_NOP) continue;
+			r = (uint32_t)t; x = (int)((t >> 32) & 0xffffu); min_intv = (uint32_t)((t >> 48) & 0x3fffu);
+			uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
+			rd.start(A.seq, rb, x);
+			lep = A.lep + tslot * A.lep_stride; n = 0;
+			if (kind == TK_ROUND3) { // find the first start (bwamem.c:255-256)
+				while (x < len && rd.at(x) > 3) ++x;
+				if (x >= len) continue;
+			}
+			ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
+			active = true;
+		}
+		uint32_t b = i < len ? rd.at(i) : 4u;
+		if (kind == TK_ROUND3) { // bwt.c:366-377
+			if (i >= len) { active = false; continue; }
+			if (b > 3) { // restart behind the ambiguous base
+				x = i + 1;
+				while (x < len && rd.at(x) > 3) ++x;
+				if (x >= len) { active = false; continue; }
+				ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
+				continue;
+			}
+			Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
+			if (y.x2 < A.max_mem_intv && i - x >= A.min_seed_len) {
+				if (y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
+				x = i + 1;
+				while (x < len && rd.at(x) > 3) ++x;
+				if (x >= len) { active = false; continue; }
+				ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
+			} else { ik = y; ++i; }
+			continue;
+		}
+		// forward pass of an SMEM call, bwt.c:303-320
+		bool done = false; int ret = 0;
+		if (b > 3) { lep[n++] = pack_lep(ik, (uint32_t)(i < len ? i : len)); ret = i < len ? i : len; done = true; }
+		else {
+			Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
+			if (y.x2 != ik.x2) {
+				lep[n++] = pack_lep(ik, (uint32_t)i);
+				if (y.x2 < min_intv) { ret = i; done = true; }
+			}
+			if (!done) { ik = y; ++i; }
+		}
+		if (done) { // hand the list to the backward kernel of its size class
+			uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
+			unsigned long long s = atomicAdd(&A.n_b[cls], 1ull);
+			BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)ret, (uint32_t)tslot};
+			if (s < A.bq_cap) A.bq[cls * A.bq_cap + s] = bt; else atomicMax(A.err, 4ull);
+			active = false;
+		}
+	}
+	atomicAdd(A.n_queries, my_q);
+}
+
+// the call that follows a finished round-1 call: next pivot = end of the longest forward match, ambiguous bases skipped
+__device__ __forceinline__ void chain_round1(const SplitArgs &A, uint32_t r, int ret)
+{
+	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
+	while (x < len && A.seq[rb + x] > 3) ++x;
+	if (x < len) push_ftask(A, ftask_pack(r, (uint32_t)x, 1, TK_ROUND1));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int BLOCK, int G>
+__global__ __launch_bounds__(BLOCK) void bwd_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
+{
+	const DevIndex &ix = A.ix;
+	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, gbase = lane - gl; // group = G consecutive lanes of a wave
+	const uint64_t gmask = (G >= 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << gbase);
+	bool active = false, live = false;
+	uint32_t r = 0, kind = 0, min_intv = 1, pend = 0;
+	int i = 0, ret = 0, nm = 0, last_start = 0;
+	Intv e = {0, 0, 0};
+	BaseReader<-1> rd;
+	unsigned long long my_q = 0;
+
+	for (;;) {
+		if (!active) { // group-uniform: the group's first lane pulls a task and shares it
+			unsigned long long t = 0;
+			if (gl == 0) t = atomicAdd(A.task_ctr, 1ull);
+			t = __shfl(t, (int)gbase);
+			if (t >= n_tasks) break;
+			BTask bt = bq[t];
+			r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
+			int x = bt.x, n = bt.n;
+			live = (int)gl < n;
+			if (live) unpack_lep(A.lep[(size_t)bt.slot * A.lep_stride + (n - 1 - (int)gl)], e, pend);
+			rd.start(A.seq, A.off[r], x - 1);
+			i = x - 1; nm = 0; last_start = 0;
+			active = true;
+		}
+		uint32_t b = i < 0 ? 4u : rd.at(i);
+		uint64_t live_m = __ballot(live) & gmask;
+		bool end_call = false;
+		if (b > 3) { // read start or ambiguous base (bwt.c:326): every live match stops; only the longest can be new
+			int first = __ffsll((long long)live_m) - 1;
+			if ((int)lane == first && (nm == 0 || i + 1 < last_start)) emit_smem(A, r, kind, e, i + 1, pend);
+			end_call = true;
+		} else {
+			Intv y = e;
+			if (live) { y = extend1<true>(ix, e, (int)b); ++my_q; }
+			bool stop = live && y.x2 < min_intv, cand = live && !stop;
+			uint64_t cand_m = __ballot(cand) & gmask;
+			int first = __ffsll((long long)live_m) - 1;
+			// bwt.c:328-336: the first live match is an SMEM if it stops here (nothing longer survived) and is not contained
+			bool first_stops = !((cand_m >> first) & 1ull);
+			if (first_stops && (nm == 0 || i + 1 < last_start)) {
+				if ((int)lane == first) emit_smem(A, r, kind, e, i + 1, pend);
+				++nm; last_start = i + 1;
+			}
+			// bwt.c:337-340: keep a surviving match unless its size equals that of the previous surviving one
+			uint64_t before = cand_m & ((1ull << lane) - 1ull);
+			int prev = before ? 63 - __clzll((long long)before) : (int)lane;
+			uint64_t prev_x2 = __shfl(y.x2, prev);
+			bool keep = cand && (before == 0 || y.x2 != prev_x2);
+			live = keep; e = y;
+			if ((__ballot(keep) & gmask) == 0) end_call = true; else --i;
+		}
+		if (end_call) {
+			if (kind == TK_ROUND1 && gl == 0) chain_round1(A, r, ret);
+			active = false;
+		}
+	}
+	atomicAdd(A.n_queries, my_q);
+}
+
+// one lane, list in HBM, compacted in place (calls with more than 64 LEPs: tandem arrays, very long reads)
+__global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
+{
+	const DevIndex &ix = A.ix;
+	unsigned long long my_q = 0;
+	for (;;) {
+		unsigned long long t = atomicAdd(A.task_ctr, 1ull);
+		if (t >= n_tasks) break;
+		BTask bt = bq[t];
+		uint32_t r = bt.r, kind = bt.mi_kind >> 14, min_intv = bt.mi_kind & 0x3fffu;
+		uint4 *lep = A.lep + (size_t)bt.slot * A.lep_stride;
+		uint64_t rb = A.off[r];
+		int n = bt.n, lo = 0, nm = 0, last_start = 0;
+		for (int i = (int)bt.x - 1; i >= -1; --i) {
+			uint32_t b = i < 0 ? 4u : A.seq[rb + i];
+			int w = n; bool kept = false; uint64_t last_kept = 0;
+			for (int j = n - 1; j >= lo; --j) {
+				Intv p; uint32_t pend; unpack_lep(lep[j], p, pend);
+				Intv y = p;
+				if (b <= 3) { y = extend1<true>(ix, p, (int)b); ++my_q; }
+				if (b > 3 || y.x2 < min_intv) {
+					if (!kept && (nm == 0 || i + 1 < last_start)) { emit_smem(A, r, kind, p, i + 1, pend); ++nm; last_start = i + 1; }
+				} else if (!kept || y.x2 != last_kept) { lep[--w] = pack_lep(y, pend); kept = true; last_kept = y.x2; }
+			}
+			if (!kept) break;
+			lo = w;
+		}
+		if (kind == TK_ROUND1) chain_round1(A, r, bt.ret);
+	}
+	atomicAdd(A.n_queries, my_q);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-read sort by info (comp_seed.cpp:2301) + CSR compaction; a read's mems beyond `cap` come from the overflow
+// records, which have been sorted by read id
+__device__ __forceinline__ const OutMem &mem_at(const OutMem *src, uint32_t cap, const OvfRec *ovf, const uint32_t *ovf_idx, uint64_t olo, uint32_t a)
+{
+	return a < cap ? src[a] : ovf[ovf_idx[olo + (a - cap)]].m;
+}
+__global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uint32_t cap, const OvfRec *ovf, const uint32_t *ovf_key,
+                                     const uint32_t *ovf_idx, uint64_t n_ovf, const uint64_t *mem_off, int64_t n_reads, OutMem *mems)
+{
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	uint32_t n = cnt[r];
+	const OutMem *src = raw + (size_t)r * cap;
+	uint64_t olo = 0;
+	if (n > cap) { // lower bound of r among the sorted overflow keys
+		uint64_t lo = 0, hi = n_ovf;
+		while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ovf_key[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
+		olo = lo;
+	}
+	OutMem *dst = mems + mem_off[r];
+	for (uint32_t a = 0; a < n; ++a) {
+		OutMem ma = mem_at(src, cap, ovf, ovf_idx, olo, a);
+		uint32_t rank = 0;
+		for (uint32_t b = 0; b < n; ++b) { uint64_t kb = mem_at(src, cap, ovf, ovf_idx, olo, b).info; rank += (kb < ma.info) || (kb == ma.info && b < a); }
+		dst[rank] = ma;
+	}
+}
+__global__ void ovf_keys_kernel(const OvfRec *ovf, uint64_t n, uint32_t *key, uint32_t *idx)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	key[t] = ovf[t].r; idx[t] = (uint32_t)t;
+}
+
+} // namespace csd

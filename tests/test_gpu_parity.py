@@ -151,3 +151,20 @@ def test_sampled_sa_walk_path(monkeypatch):
         _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
     assert e.stats()["overflow_reads"] > 0
     e.close(); ix.close()
+
+
+@pytest.mark.parametrize("mode", ["fused", "split"])
+def test_both_smem_kernels_match_golden(monkeypatch, mode):
+    """the fused one-lane-per-read kernel and the forward / cooperative-backward kernels are two independent
+    implementations of the same three rounds: both must reproduce the reference bit for bit"""
+    import compseed_amd as ca
+    monkeypatch.setenv("CS_SMEM_MODE", mode)
+    monkeypatch.setenv("CS_MEM_CAP", "6")        # most reads overflow their first 6 slots: exercises both overflow paths
+    monkeypatch.setenv("CS_LEP_ARENA_MB", "1")   # tiny LEP arena: the forward queue is processed in many chunks
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0)
+    for name, pname in _data.golden_runs():
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+    e.close(); ix.close()
