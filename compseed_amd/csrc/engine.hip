@@ -420,7 +420,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	uint64_t chunk = std::max<uint64_t>(4096, e->lep_arena_bytes / ((size_t)stride * sizeof(uint4)));
 	chunk = std::min<uint64_t>(chunk, fq_cap);
 	CS_TRY(e->d_fqA.reserve(fq_cap)); CS_TRY(e->d_fqB.reserve(fq_cap));
-	CS_TRY(e->d_bq.reserve(4 * chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
+	CS_TRY(e->d_bq.reserve(chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
 	CS_TRY(e->d_ovfrec.reserve(ovf_cap));
 	unsigned long long *C = e->d_sctr.p, *H = e->h_sctr.p; // [0] task ctr [1] next-queue length [2..5] backward queues [6] overflow mems [7] error [8] queries
 	HIP_TRY(hipMemsetAsync(C, 0, 16 * sizeof(unsigned long long), s));
@@ -433,7 +433,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.min_seed_len = par->min_seed_len;
 	A.split_len = (int)(1.0 * par->min_seed_len * par->split_factor + .499); // comp_seed.cpp:2279 (double arithmetic)
 	A.split_width = (uint32_t)par->split_width; A.max_mem_intv = par->max_mem_intv;
-	A.bq = e->d_bq.p; A.n_b = C + 2; A.bq_cap = chunk;
+	A.bq = e->d_bq.p;
 	A.lep = e->d_lep.p; A.lep_stride = stride;
 	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7;
 	A.fq_cap = fq_cap; A.n_f_next = C + 1;
@@ -445,29 +445,31 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	uint64_t n_f = 2 * (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
 		A.fq_next = nxt;
-		for (uint64_t c0 = 0; c0 < n_f; c0 += chunk) {
+		for (uint64_t c0 = 0; c0 < n_f; ) {
+			// iteration 0: the second half of the queue holds the round-3 chains, which use no LEP list => one launch
 			uint64_t cn = std::min<uint64_t>(chunk, n_f - c0);
+			if (iter == 0) cn = c0 < (uint64_t)nb ? std::min<uint64_t>(chunk, (uint64_t)nb - c0) : n_f - c0;
 			A.fq = cur + c0; A.n_f = cn;
 			HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-			HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
+			bool r3_only = (iter == 0 && c0 >= (uint64_t)nb);
+			if (!r3_only) HIP_TRY(hipMemsetAsync(e->d_bq.p, 0xff, cn * sizeof(BTask), s)); // slots without a call stay "no class"
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
 			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-			HIP_TRY(hipStreamSynchronize(s));
-			if (H[7]) return 1;
-			for (int cls = 0; cls < 4; ++cls) {
-				uint64_t nbt = H[2 + cls];
-				if (!nbt) continue;
-				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-				const BTask *q = e->d_bq.p + (size_t)cls * chunk;
+			if (!r3_only) { // every size class scans the chunk's slots and takes its own calls
 				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
-				if (cls == 0)      hipLaunchKernelGGL((bwd_kernel<256, 16>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 15) / 16)), dim3(256), 0, s, A, q, nbt);
-				else if (cls == 1) hipLaunchKernelGGL((bwd_kernel<256, 32>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 7) / 8)), dim3(256), 0, s, A, q, nbt);
-				else if (cls == 2) hipLaunchKernelGGL((bwd_kernel<256, 64>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 3) / 4)), dim3(256), 0, s, A, q, nbt);
-				else               hipLaunchKernelGGL(bwd_serial_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (nbt + 63) / 64)), dim3(64), 0, s, A, q, nbt);
+				const BTask *q = e->d_bq.p;
+				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+				hipLaunchKernelGGL((bwd_kernel<256, 16>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A, q, cn);
+				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+				hipLaunchKernelGGL((bwd_kernel<256, 32>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), dim3(256), 0, s, A, q, cn);
+				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+				hipLaunchKernelGGL((bwd_kernel<256, 64>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 3) / 4)), dim3(256), 0, s, A, q, cn);
+				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+				hipLaunchKernelGGL(bwd_serial_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 63) / 64)), dim3(64), 0, s, A, q, cn);
 				HIP_TRY(hipGetLastError());
 			}
+			c0 += cn;
 		}
 		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
@@ -475,7 +477,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		n_f = H[1];
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
 		std::swap(cur, nxt);
-		if (iter > 70000) return fail(CS_EDEVICE, "SMEM task chain did not terminate");
+		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
 	HIP_TRY(hipEventRecord(e->ev[1], s));
 	HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

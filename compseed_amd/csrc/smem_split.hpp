@@ -37,7 +37,8 @@ __device__ __host__ __forceinline__ uint64_t ftask_pack(uint32_t r, uint32_t x, 
 	return (uint64_t)r | (uint64_t)x << 32 | (uint64_t)min_intv << 48 | (uint64_t)kind << 62;
 }
 
-struct BTask { uint32_t r; uint16_t x, mi_kind, n, ret; uint32_t slot; }; // 16 bytes; slot = index of the LEP list
+struct BTask { uint32_t r; uint16_t x, mi_kind, n, ret; uint32_t cls; };  // 16 bytes, stored at the forward task's slot;
+                                                                           // cls = size class 0..3, 0xffffffff = no call
 struct OvfRec { OutMem m; uint32_t r, pad; };                              // a mem beyond a read's first `cap`
 
 struct SplitArgs {
@@ -52,7 +53,7 @@ struct SplitArgs {
 	uint64_t  max_mem_intv;
 	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
 	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
-	BTask    *bq; unsigned long long *n_b; uint64_t bq_cap;   // 4 classes: bq + c*bq_cap, n_b[c]
+	BTask    *bq;                                     // backward task of forward task t: bq[t] (no atomics: 1:1)
 	uint4    *lep; uint32_t lep_stride;               // LEP list of forward task t: lep + t*lep_stride
 	unsigned long long *task_ctr;
 	unsigned long long *n_queries;
@@ -69,19 +70,22 @@ __device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const I
 		if (s < A.ovf_cap) { OvfRec o = {m, r, 0}; A.ovf[s] = o; } else atomicMax(A.err, 1ull);
 	}
 }
-__device__ __forceinline__ void push_ftask(const SplitArgs &A, uint64_t t)
+__device__ __forceinline__ void push_ftask(const SplitArgs &A, uint64_t t) // one atomic per task: rare paths only
 {
 	unsigned long long s = atomicAdd(A.n_f_next, 1ull);
 	if (s < A.fq_cap) A.fq_next[s] = t; else atomicMax(A.err, 2ull);
 }
-// an SMEM of a round-1/2 call: length filter (bwamem.c:232,246), and for round 1 the re-seeding call it triggers
-__device__ __forceinline__ void emit_smem(const SplitArgs &A, uint32_t r, uint32_t kind, const Intv &v, int beg, uint32_t end)
+constexpr uint64_t FTASK_NONE = ~0ull; // kind bits = TK_NOP
+// an SMEM of a round-1/2 call: length filter (bwamem.c:232,246); returns the re-seeding call a round-1 SMEM triggers
+// (bwamem.c:241-249) or FTASK_NONE
+__device__ __forceinline__ uint64_t emit_smem(const SplitArgs &A, uint32_t r, uint32_t kind, const Intv &v, int beg, uint32_t end)
 {
 	int len = (int)end - beg;
-	if (len < A.min_seed_len) return;
+	if (len < A.min_seed_len) return FTASK_NONE;
 	emit_mem(A, r, v, (uint32_t)beg, end);
 	if (kind == TK_ROUND1 && len >= A.split_len && v.x2 <= A.split_width)
-		push_ftask(A, ftask_pack(r, (uint32_t)(beg + (int)end) >> 1, (uint32_t)v.x2 + 1, TK_ROUND2));
+		return ftask_pack(r, (uint32_t)(beg + (int)end) >> 1, (uint32_t)v.x2 + 1, TK_ROUND2);
+	return FTASK_NONE;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -92,8 +96,67 @@ __global__ void init_tasks_kernel(const SplitArgs A, uint64_t *fq)
 	if (r >= A.n_reads) return;
 	uint64_t b = A.off[r]; int len = (int)(A.off[r + 1] - b), x = 0;
 	while (x < len && A.seq[b + x] > 3) ++x;
-	fq[2 * r] = x < len ? ftask_pack((uint32_t)r, (uint32_t)x, 1, TK_ROUND1) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
-	fq[2 * r + 1] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+	// the round-1 calls fill the first half of the queue, the round-3 chains the second half (they need no LEP list)
+	fq[r] = x < len ? ftask_pack((uint32_t)r, (uint32_t)x, 1, TK_ROUND1) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+	fq[A.n_reads + r] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+}
+
+// Task dispenser.  One returning atomic on a single word costs ~11 ns and the word saturates near 88 M dequeues/s
+// (MI355X_MICROARCH.md "dequeue"), far below the millions of short tasks per launch here, so a wave draws REFILL task
+// ids at a time with ONE atomic and hands them to its lanes with a ballot + popcount.  All state is wave-uniform.
+struct WavePool { uint64_t cur, end; bool exhausted; };
+
+template <int REFILL>
+__device__ __forceinline__ bool pool_take(WavePool &P, bool want, unsigned long long *ctr, uint64_t n_tasks, uint64_t &task)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t m = __ballot(want);
+	if (m == 0) return false;
+	if (P.cur == P.end && !P.exhausted) {
+		int src = __ffsll((long long)m) - 1;
+		unsigned long long base = 0;
+		if ((int)lane == src) base = atomicAdd(ctr, (unsigned long long)REFILL);
+		base = __shfl(base, src);
+		if (base >= n_tasks) P.exhausted = true;
+		else { P.cur = base; P.end = base + REFILL < n_tasks ? base + REFILL : n_tasks; }
+	}
+	uint64_t avail = P.end - P.cur, cnt = (uint64_t)__popcll(m);
+	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+	task = P.cur + rank;
+	P.cur += cnt < avail ? cnt : avail;
+	return want && rank < avail;
+}
+
+// The reverse direction: a wave reserves RES slots of the next forward queue with one atomic and its lanes fill them
+// (ballot + popcount); slots left over when the wave moves on are filled with no-op tasks.
+struct WaveOut { uint64_t cur, end; };
+template <int RES>
+__device__ __forceinline__ void wave_push(WaveOut &O, bool want, uint64_t task, const SplitArgs &A)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t m = __ballot(want);
+	if (m == 0) return;
+	uint64_t cnt = (uint64_t)__popcll(m);
+	if (O.end - O.cur < cnt) {
+		uint64_t rem = O.end - O.cur;
+		if (lane < rem) A.fq_next[O.cur + lane] = FTASK_NONE;
+		int src = __ffsll((long long)m) - 1;
+		unsigned long long base = 0;
+		if ((int)lane == src) base = atomicAdd(A.n_f_next, (unsigned long long)RES);
+		base = __shfl(base, src);
+		if (base + RES > A.fq_cap) { if ((int)lane == src) atomicMax(A.err, 2ull); O.cur = O.end = 0; return; }
+		O.cur = base; O.end = base + RES;
+	}
+	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+	if (want) A.fq_next[O.cur + rank] = task;
+	O.cur += cnt;
+}
+__device__ __forceinline__ void wave_push_finish(WaveOut &O, const SplitArgs &A)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t rem = O.end - O.cur;
+	if (lane < rem) A.fq_next[O.cur + lane] = FTASK_NONE;
+	O.cur = O.end;
 }
 
 // sequential reader of a read's bases: 8-base window in a register, the next window prefetched when one is entered
@@ -132,79 +195,70 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 	BaseReader<1> rd;
 	uint4 *lep = nullptr;
 	unsigned long long my_q = 0;
+	WavePool P = {0, 0, false};
 
 	for (;;) {
-		if (!active) {
-			tslot = atomicAdd(A.task_ctr, 1ull);
-			if (tslot >= A.n_f) break;
+		uint64_t t_id = 0;
+		bool got = pool_take<256>(P, !active, A.task_ctr, A.n_f, t_id);
+		if (!active && got) {
+			tslot = t_id;
 			uint64_t t = A.fq[tslot];
 			kind = (uint32_t)(t >> 62);
-			if (kind == TK_NOP) continue;
 			r = (uint32_t)t; x = (int)((t >> 32) & 0xffffu); min_intv = (uint32_t)((t >> 48) & 0x3fffu);
-			uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
-			rd.start(A.seq, rb, x);
-			lep = A.lep + tslot * A.lep_stride; n = 0;
-			if (kind == TK_ROUND3) { // find the first start (bwamem.c:255-256)
-				while (x < len && rd.at(x) > 3) ++x;
-				if (x >= len) continue;
+			if (kind != TK_NOP && (int64_t)r < A.n_reads) {
+				uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
+				if (x < len) {
+					rd.start(A.seq, rb, x);
+					lep = A.lep + tslot * A.lep_stride; n = 0;
+					if (kind == TK_ROUND3) while (x < len && rd.at(x) > 3) ++x; // first start (bwamem.c:255-256)
+					if (x < len) { ik = set_intv(ix, (int)rd.at(x)); i = x + 1; active = true; }
+				}
 			}
-			ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
-			active = true;
 		}
+		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
+		if (!active) continue;
+		// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
 		uint32_t b = i < len ? rd.at(i) : 4u;
-		if (kind == TK_ROUND3) { // bwt.c:366-377
-			if (i >= len) { active = false; continue; }
-			if (b > 3) { // restart behind the ambiguous base
-				x = i + 1;
-				while (x < len && rd.at(x) > 3) ++x;
-				if (x >= len) { active = false; continue; }
-				ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
-				continue;
-			}
-			Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
-			if (y.x2 < A.max_mem_intv && i - x >= A.min_seed_len) {
-				if (y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
-				x = i + 1;
-				while (x < len && rd.at(x) > 3) ++x;
-				if (x >= len) { active = false; continue; }
-				ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
-			} else { ik = y; ++i; }
+		Intv y = ik;
+		if (b <= 3) { y = extend1<false>(ix, ik, 3 - (int)b); ++my_q; }
+
+		if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
+			if (b <= 3 && !(y.x2 < A.max_mem_intv && i - x >= A.min_seed_len)) { ik = y; ++i; continue; }
+			if (b > 3 && i >= len) { active = false; continue; }
+			if (b <= 3 && y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
+			x = i + 1; // restart behind the seed / the ambiguous base
+			while (x < len && rd.at(x) > 3) ++x;
+			if (x >= len) { active = false; continue; }
+			ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
 			continue;
 		}
-		// forward pass of an SMEM call, bwt.c:303-320
-		bool done = false; int ret = 0;
-		if (b > 3) { lep[n++] = pack_lep(ik, (uint32_t)(i < len ? i : len)); ret = i < len ? i : len; done = true; }
-		else {
-			Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
-			if (y.x2 != ik.x2) {
-				lep[n++] = pack_lep(ik, (uint32_t)i);
-				if (y.x2 < min_intv) { ret = i; done = true; }
-			}
-			if (!done) { ik = y; ++i; }
-		}
-		if (done) { // hand the list to the backward kernel of its size class
-			uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
-			unsigned long long s = atomicAdd(&A.n_b[cls], 1ull);
-			BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)ret, (uint32_t)tslot};
-			if (s < A.bq_cap) A.bq[cls * A.bq_cap + s] = bt; else atomicMax(A.err, 4ull);
-			active = false;
-		}
+		// ---- forward pass of an SMEM call, bwt.c:303-320
+		bool done = false;
+		if (b > 3) { lep[n++] = pack_lep(ik, (uint32_t)i); done = true; }       // read end (i == len) or ambiguous base
+		else if (y.x2 != ik.x2) { lep[n++] = pack_lep(ik, (uint32_t)i); done = y.x2 < min_intv; }
+		if (!done) { ik = y; ++i; continue; }
+		// hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
+		uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
+		BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
+		A.bq[tslot] = bt;
+		active = false;
 	}
 	atomicAdd(A.n_queries, my_q);
 }
 
 // the call that follows a finished round-1 call: next pivot = end of the longest forward match, ambiguous bases skipped
-__device__ __forceinline__ void chain_round1(const SplitArgs &A, uint32_t r, int ret)
+__device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r, int ret)
 {
 	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
 	while (x < len && A.seq[rb + x] > 3) ++x;
-	if (x < len) push_ftask(A, ftask_pack(r, (uint32_t)x, 1, TK_ROUND1));
+	return x < len ? ftask_pack(r, (uint32_t)x, 1, TK_ROUND1) : FTASK_NONE;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int BLOCK, int G>
 __global__ __launch_bounds__(BLOCK) void bwd_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
 {
+	constexpr uint32_t MYCLS = G == 16 ? 0u : G == 32 ? 1u : 2u;
 	const DevIndex &ix = A.ix;
 	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, gbase = lane - gl; // group = G consecutive lanes of a wave
 	const uint64_t gmask = (G >= 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << gbase);
@@ -214,54 +268,68 @@ __global__ __launch_bounds__(BLOCK) void bwd_kernel(const SplitArgs A, const BTa
 	Intv e = {0, 0, 0};
 	BaseReader<-1> rd;
 	unsigned long long my_q = 0;
+	WavePool P = {0, 0, false};
+	WaveOut O = {0, 0};
 
+	// Every lane of the wave stays in the loop until the whole wave is done, and every lane executes the two dispenser
+	// calls at the top and the bottom of each iteration, so their wave-uniform state stays identical in all lanes.
 	for (;;) {
-		if (!active) { // group-uniform: the group's first lane pulls a task and shares it
-			unsigned long long t = 0;
-			if (gl == 0) t = atomicAdd(A.task_ctr, 1ull);
-			t = __shfl(t, (int)gbase);
-			if (t >= n_tasks) break;
-			BTask bt = bq[t];
-			r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
-			int x = bt.x, n = bt.n;
-			live = (int)gl < n;
-			if (live) unpack_lep(A.lep[(size_t)bt.slot * A.lep_stride + (n - 1 - (int)gl)], e, pend);
-			rd.start(A.seq, A.off[r], x - 1);
-			i = x - 1; nm = 0; last_start = 0;
-			active = true;
-		}
-		uint32_t b = i < 0 ? 4u : rd.at(i);
-		uint64_t live_m = __ballot(live) & gmask;
-		bool end_call = false;
-		if (b > 3) { // read start or ambiguous base (bwt.c:326): every live match stops; only the longest can be new
-			int first = __ffsll((long long)live_m) - 1;
-			if ((int)lane == first && (nm == 0 || i + 1 < last_start)) emit_smem(A, r, kind, e, i + 1, pend);
-			end_call = true;
-		} else {
-			Intv y = e;
-			if (live) { y = extend1<true>(ix, e, (int)b); ++my_q; }
-			bool stop = live && y.x2 < min_intv, cand = live && !stop;
-			uint64_t cand_m = __ballot(cand) & gmask;
-			int first = __ffsll((long long)live_m) - 1;
-			// bwt.c:328-336: the first live match is an SMEM if it stops here (nothing longer survived) and is not contained
-			bool first_stops = !((cand_m >> first) & 1ull);
-			if (first_stops && (nm == 0 || i + 1 < last_start)) {
-				if ((int)lane == first) emit_smem(A, r, kind, e, i + 1, pend);
-				++nm; last_start = i + 1;
+		uint64_t t = 0;
+		bool got = pool_take<8 * (64 / G)>(P, !active && gl == 0, A.task_ctr, n_tasks, t);
+		if (!active) { // group-uniform: the group's first lane drew a task (or not) and shares it
+			got = __shfl((int)got, (int)gbase) != 0;
+			t = __shfl((unsigned long long)t, (int)gbase);
+			if (got) {
+				BTask bt = bq[t];
+				if (bt.cls == MYCLS) { // otherwise: another size class's call, or no call in this slot
+					r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
+					int x = bt.x, n = bt.n;
+					live = (int)gl < n;
+					if (live) unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend);
+					rd.start(A.seq, A.off[r], x - 1);
+					i = x - 1; nm = 0; last_start = 0;
+					active = true;
+				}
 			}
-			// bwt.c:337-340: keep a surviving match unless its size equals that of the previous surviving one
-			uint64_t before = cand_m & ((1ull << lane) - 1ull);
-			int prev = before ? 63 - __clzll((long long)before) : (int)lane;
-			uint64_t prev_x2 = __shfl(y.x2, prev);
-			bool keep = cand && (before == 0 || y.x2 != prev_x2);
-			live = keep; e = y;
-			if ((__ballot(keep) & gmask) == 0) end_call = true; else --i;
 		}
-		if (end_call) {
-			if (kind == TK_ROUND1 && gl == 0) chain_round1(A, r, ret);
-			active = false;
+		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
+		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE; // forward tasks this lane spawns in this step
+		if (active) {
+			uint32_t b = i < 0 ? 4u : rd.at(i);
+			uint64_t live_m = __ballot(live) & gmask;
+			int first = __ffsll((long long)live_m) - 1; // the longest live match of the group
+			bool end_call = false;
+			if (b > 3) { // read start or ambiguous base (bwt.c:326): every live match stops; only the longest can be new
+				if ((int)lane == first && (nm == 0 || i + 1 < last_start)) push0 = emit_smem(A, r, kind, e, i + 1, pend);
+				end_call = true;
+			} else {
+				Intv y = e;
+				if (live) { y = extend1<true>(ix, e, (int)b); ++my_q; }
+				bool stop = live && y.x2 < min_intv, cand = live && !stop;
+				uint64_t cand_m = __ballot(cand) & gmask;
+				// bwt.c:328-336: the first live match is an SMEM if it stops here (nothing longer survived) and is not contained
+				bool first_stops = !((cand_m >> first) & 1ull);
+				if (first_stops && (nm == 0 || i + 1 < last_start)) {
+					if ((int)lane == first) push0 = emit_smem(A, r, kind, e, i + 1, pend);
+					++nm; last_start = i + 1;
+				}
+				// bwt.c:337-340: keep a surviving match unless its size equals that of the previous surviving one
+				uint64_t before = cand_m & ((1ull << lane) - 1ull);
+				int prev = before ? 63 - __clzll((long long)before) : (int)lane;
+				uint64_t prev_x2 = __shfl(y.x2, prev);
+				bool keep = cand && (before == 0 || y.x2 != prev_x2);
+				live = keep; e = y;
+				if (cand_m == 0) end_call = true; else --i; // the first surviving match is always kept
+			}
+			if (end_call) {
+				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(A, r, ret);
+				active = false;
+			}
 		}
+		wave_push<32>(O, push0 != FTASK_NONE, push0, A);
+		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
 	}
+	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 }
 
@@ -274,8 +342,9 @@ __global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n
 		unsigned long long t = atomicAdd(A.task_ctr, 1ull);
 		if (t >= n_tasks) break;
 		BTask bt = bq[t];
+		if (bt.cls != 3u) continue;
 		uint32_t r = bt.r, kind = bt.mi_kind >> 14, min_intv = bt.mi_kind & 0x3fffu;
-		uint4 *lep = A.lep + (size_t)bt.slot * A.lep_stride;
+		uint4 *lep = A.lep + (size_t)t * A.lep_stride;
 		uint64_t rb = A.off[r];
 		int n = bt.n, lo = 0, nm = 0, last_start = 0;
 		for (int i = (int)bt.x - 1; i >= -1; --i) {
@@ -286,13 +355,17 @@ __global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n
 				Intv y = p;
 				if (b <= 3) { y = extend1<true>(ix, p, (int)b); ++my_q; }
 				if (b > 3 || y.x2 < min_intv) {
-					if (!kept && (nm == 0 || i + 1 < last_start)) { emit_smem(A, r, kind, p, i + 1, pend); ++nm; last_start = i + 1; }
+					if (!kept && (nm == 0 || i + 1 < last_start)) {
+						uint64_t t2 = emit_smem(A, r, kind, p, i + 1, pend);
+						if (t2 != FTASK_NONE) push_ftask(A, t2);
+						++nm; last_start = i + 1;
+					}
 				} else if (!kept || y.x2 != last_kept) { lep[--w] = pack_lep(y, pend); kept = true; last_kept = y.x2; }
 			}
 			if (!kept) break;
 			lo = w;
 		}
-		if (kind == TK_ROUND1) chain_round1(A, r, bt.ret);
+		if (kind == TK_ROUND1) { uint64_t t2 = chain_round1(A, r, bt.ret); if (t2 != FTASK_NONE) push_ftask(A, t2); }
 	}
 	atomicAdd(A.n_queries, my_q);
 }
