@@ -105,7 +105,7 @@ struct cs_engine {
 	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
 	int smem_mode = 1;          // 1 = split kernels (default), 0 = fused one-lane-per-read kernel (CS_SMEM_MODE=fused)
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
-	size_t lep_arena_bytes = (size_t)12 << 30;
+	size_t lep_arena_bytes = (size_t)32 << 30;
 	cs_stats_t st{};
 	uint32_t cap = 64;          // mems per read kept by the first pass
 	size_t max_raw_bytes = (size_t)24 << 30;
@@ -215,7 +215,7 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	{
 		int nb = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fwd_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_fwd = std::min(nb, 8);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_kernel<256, 16>, 256, 0) == hipSuccess && nb > 0) e->occ_bwd = std::min(nb, 8);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_all_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_bwd = std::min(nb, 8);
 		(void)hipGetLastError();
 	}
 	if (const char *m = getenv("CS_SMEM_MODE")) e->smem_mode = strcmp(m, "fused") == 0 ? 0 : 1;
@@ -456,17 +456,11 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
 			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
 			HIP_TRY(hipGetLastError());
-			if (!r3_only) { // every size class scans the chunk's slots and takes its own calls
+			if (!r3_only) { // one launch works through all four size classes of the chunk's backward sweeps
 				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
-				const BTask *q = e->d_bq.p;
-				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-				hipLaunchKernelGGL((bwd_kernel<256, 16>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A, q, cn);
-				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-				hipLaunchKernelGGL((bwd_kernel<256, 32>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), dim3(256), 0, s, A, q, cn);
-				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-				hipLaunchKernelGGL((bwd_kernel<256, 64>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 3) / 4)), dim3(256), 0, s, A, q, cn);
-				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-				hipLaunchKernelGGL(bwd_serial_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 63) / 64)), dim3(64), 0, s, A, q, cn);
+				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
+				hipLaunchKernelGGL((bwd_all_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A,
+				                   (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
 			}
 			c0 += cn;

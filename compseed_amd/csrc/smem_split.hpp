@@ -255,8 +255,9 @@ __device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int BLOCK, int G>
-__global__ __launch_bounds__(BLOCK) void bwd_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
+template <int G>
+__device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
+                                               unsigned long long &my_q)
 {
 	constexpr uint32_t MYCLS = G == 16 ? 0u : G == 32 ? 1u : 2u;
 	const DevIndex &ix = A.ix;
@@ -267,32 +268,52 @@ __global__ __launch_bounds__(BLOCK) void bwd_kernel(const SplitArgs A, const BTa
 	int i = 0, ret = 0, nm = 0, last_start = 0;
 	Intv e = {0, 0, 0};
 	BaseReader<-1> rd;
-	unsigned long long my_q = 0;
-	WavePool P = {0, 0, false};
-	WaveOut O = {0, 0};
 
-	// Every lane of the wave stays in the loop until the whole wave is done, and every lane executes the two dispenser
-	// calls at the top and the bottom of each iteration, so their wave-uniform state stays identical in all lanes.
+	// Every lane of the wave stays in the loop until the whole wave is done, and every lane executes the dispenser code at
+	// the top and the bottom of each iteration, so its wave-uniform state stays identical in all lanes.
+	//
+	// Task acquisition: the backward tasks sit in the forward tasks' slots, each tagged with its size class.  A wave takes
+	// 64 consecutive slots with one atomic, its 64 lanes read the 64 tags in one coalesced load, and a ballot gives the mask
+	// of slots that belong to this kernel's class; idle groups then pop slots off that mask.  Skipping foreign slots costs
+	// nothing per slot, so every size class can scan the whole queue.
+	uint64_t batch_base = 0, avail_m = 0; bool exhausted = false;
 	for (;;) {
-		uint64_t t = 0;
-		bool got = pool_take<8 * (64 / G)>(P, !active && gl == 0, A.task_ctr, n_tasks, t);
-		if (!active) { // group-uniform: the group's first lane drew a task (or not) and shares it
-			got = __shfl((int)got, (int)gbase) != 0;
-			t = __shfl((unsigned long long)t, (int)gbase);
-			if (got) {
-				BTask bt = bq[t];
-				if (bt.cls == MYCLS) { // otherwise: another size class's call, or no call in this slot
-					r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
-					int x = bt.x, n = bt.n;
-					live = (int)gl < n;
-					if (live) unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend);
-					rd.start(A.seq, A.off[r], x - 1);
-					i = x - 1; nm = 0; last_start = 0;
-					active = true;
-				}
+		uint64_t idle_m = __ballot(!active && gl == 0);
+		if (idle_m != 0 && avail_m == 0 && !exhausted) {
+			int src = __ffsll((long long)idle_m) - 1;
+			unsigned long long base = 0;
+			if ((int)lane == src) base = atomicAdd(ctr, 64ull);
+			base = __shfl(base, src);
+			if (base >= n_tasks) exhausted = true;
+			else {
+				uint64_t slot = base + lane;
+				uint32_t cls = slot < n_tasks ? bq[slot].cls : 0xffffffffu;
+				avail_m = __ballot(cls == MYCLS);
+				batch_base = base;
 			}
 		}
-		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
+		if (idle_m != 0 && avail_m != 0) {
+			// the k-th idle group (in lane order) takes the k-th set bit of avail_m
+			int k = __popcll(idle_m & ((1ull << gbase) - 1ull));
+			uint64_t m = avail_m;
+			for (int q = 0; q < k; ++q) m &= m - 1;
+			bool mine = !active && m != 0;
+			uint64_t t = batch_base + (uint64_t)(__ffsll((long long)m) - 1);
+			int taken = __popcll(idle_m), have = __popcll(avail_m);
+			if (taken > have) taken = have;
+			for (int q = 0; q < taken; ++q) avail_m &= avail_m - 1;
+			if (mine) {
+				BTask bt = bq[t];
+				r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
+				int x = bt.x, n = bt.n;
+				live = (int)gl < n;
+				if (live) unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend);
+				rd.start(A.seq, A.off[r], x - 1);
+				i = x - 1; nm = 0; last_start = 0;
+				active = true;
+			}
+		}
+		if (exhausted && avail_m == 0 && __ballot(active) == 0) break; // wave-uniform exit
 		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE; // forward tasks this lane spawns in this step
 		if (active) {
 			uint32_t b = i < 0 ? 4u : rd.at(i);
@@ -329,11 +350,97 @@ __global__ __launch_bounds__(BLOCK) void bwd_kernel(const SplitArgs A, const BTa
 		wave_push<32>(O, push0 != FTASK_NONE, push0, A);
 		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
 	}
+}
+
+// Calls with more than 64 LEPs (tandem arrays, very long reads): one WAVE per call, the list stays in HBM and every step
+// of the sweep streams the live part through the wave 64 entries at a time, longest first, compacting it in place (the
+// write index never passes below the chunk being processed).  Same rules as above; the "previous surviving size" is
+// carried from chunk to chunk.
+__device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
+                                             unsigned long long &my_q)
+{
+	const DevIndex &ix = A.ix;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+	uint64_t batch_base = 0, avail_m = 0;
+	for (;;) {
+		if (avail_m == 0) { // wave-uniform acquisition, as in bwd_groups_run
+			unsigned long long base = 0;
+			if (lane == 0) base = atomicAdd(ctr, 64ull);
+			base = __shfl(base, 0);
+			if (base >= n_tasks) break;
+			uint64_t slot = base + lane;
+			uint32_t cls = slot < n_tasks ? bq[slot].cls : 0xffffffffu;
+			avail_m = __ballot(cls == 3u);
+			batch_base = base;
+			if (avail_m == 0) continue;
+		}
+		uint64_t t = batch_base + (uint64_t)(__ffsll((long long)avail_m) - 1);
+		avail_m &= avail_m - 1;
+		BTask bt = bq[t];
+		uint32_t r = bt.r, kind = bt.mi_kind >> 14, min_intv = bt.mi_kind & 0x3fffu;
+		uint4 *lep = A.lep + (size_t)t * A.lep_stride;
+		uint64_t rb = A.off[r];
+		int n = bt.n, lo = 0, nm = 0, last_start = 0;
+		for (int i = (int)bt.x - 1; i >= -1; --i) {
+			uint32_t b = i < 0 ? 4u : A.seq[rb + i];
+			int w = n; bool first_done = false, have_prev = false; uint64_t prev_carry = 0, push0 = FTASK_NONE;
+			for (int top = n; top > lo; top -= 64) {
+				int j = top - 1 - (int)lane; bool valid = j >= lo;
+				Intv p = {0, 0, 0}; uint32_t pend = 0;
+				if (valid) unpack_lep(lep[j], p, pend);
+				Intv y = p;
+				if (valid && b <= 3) { y = extend1<true>(ix, p, (int)b); ++my_q; }
+				bool cand = valid && b <= 3 && y.x2 >= min_intv;
+				uint64_t cand_m = __ballot(cand);
+				if (!first_done) { // lane 0 of the first chunk holds the longest live match (bwt.c:328-336)
+					first_done = true;
+					if (!(cand_m & 1ull) && (nm == 0 || i + 1 < last_start)) {
+						if (lane == 0) push0 = emit_smem(A, r, kind, p, i + 1, pend);
+						++nm; last_start = i + 1;
+					}
+				}
+				uint64_t before = cand_m & lt_mask;
+				int prev = before ? 63 - __clzll((long long)before) : (int)lane;
+				uint64_t px2 = __shfl(y.x2, prev);
+				if (!before) px2 = prev_carry;
+				bool keep = cand && ((!before && !have_prev) || y.x2 != px2); // bwt.c:337-340
+				uint64_t keep_m = __ballot(keep);
+				if (keep) lep[w - 1 - __popcll(keep_m & lt_mask)] = pack_lep(y, pend);
+				w -= __popcll(keep_m);
+				if (cand_m) { have_prev = true; prev_carry = __shfl(y.x2, 63 - __clzll((long long)cand_m)); }
+			}
+			__threadfence_block(); // the compacted list is read back by other lanes of this wave in the next step
+			wave_push<32>(O, push0 != FTASK_NONE, push0, A);
+			if (w == n) break;
+			lo = w;
+		}
+		uint64_t push1 = (kind == TK_ROUND1 && lane == 0) ? chain_round1(A, r, bt.ret) : FTASK_NONE;
+		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
+	}
+}
+
+// All backward work of one forward launch in ONE kernel: every wave works through the four size classes, starting with
+// a different one depending on its workgroup, so all classes progress at once and a wave whose class runs dry moves on
+// to the next instead of idling through that class's tail.  ctrs[c] is the slot counter of class c.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 4) void bwd_all_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
+{
+	WaveOut O = {0, 0};
+	unsigned long long my_q = 0;
+	const uint32_t role = blockIdx.x & 7u, first = role < 5 ? 0u : role - 4u; // 5/8 of the workgroups start on the <=16 class
+	for (uint32_t k = 0; k < 4; ++k) {
+		uint32_t c = (first + k) & 3u;
+		if (c == 0) bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q);
+		else if (c == 1) bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q);
+		else if (c == 2) bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q);
+		else bwd_wide_run(A, bq, n_tasks, ctrs + 3, O, my_q);
+	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 }
 
-// one lane, list in HBM, compacted in place (calls with more than 64 LEPs: tandem arrays, very long reads)
+// one lane, list in HBM, compacted in place (reference form of the sweep; kept for A/B tests of the wide path)
 __global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
 {
 	const DevIndex &ix = A.ix;
