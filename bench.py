@@ -148,12 +148,24 @@ def main():
         unc = oidx.seed_batch(hb, ho, opar, mode=0, want_sal=False, threads=min(16, len(os.sched_getaffinity(0))))["stats"]
         per_read = (64.0 * ws["bwt_blocks"] + 32.0 * ws["n_mems"]) / nchk + args.read_len
         per_read_unc = (64.0 * unc["bwt_blocks_uncached"] + 32.0 * ws["n_mems"]) / nchk + args.read_len
-        launches = max(1, st["seed_kernel_launches"])
+        # The SMEM stage is the dominant device work.  In the default (split) mode one pass over a batch = a short chain of
+        # fwd_kernel / bwd_all_kernel launches; their summed duration per pass is measured with HIP events on the engine's
+        # stream (first launch to last) and must agree with rocprofv3's TotalDurationNs(fwd_kernel)+(bwd_all_kernel) per pass.
+        launches = max(1, st["seed_kernel_launches"])          # passes of the stage (1 per step unless the batch is split)
         kern_ms = st["seed_kernel_ms"] / launches
         reads_per_launch = args.reads * args.steps / launches
         achieved = per_read * reads_per_launch / (kern_ms * 1e-3) / 1e9
+        fused = os.environ.get("CS_SMEM_MODE", "") == "fused"
+        pmc = None
+        try:  # HBM bytes per pass from the committed PMC run of this workload (tools/pmc.sh), if there is one
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = "%g_%d_%d" % (args.genome_mbp, args.reads, args.read_len)
+            pmc = pm.get(key, {}).get("smem_stage_bytes_per_pass")
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "smem_kernel", "kernel_ms_per_launch": kern_ms, "launches": launches,
+                           "traffic": pmc, "kernel": "smem_kernel" if fused else "SMEM stage = fwd_kernel + bwd_all_kernel launches of one pass",
+                           "kernel_ms_per_launch": kern_ms, "launches": launches,
                            "algorithmic_bytes_per_read": per_read, "uncached_bytes_per_read": per_read_unc,
                            "bwt_extend_queries_per_read": st["bwt_queries"] / (args.reads * args.steps),
                            "sal_ms_per_step": st["sal_kernel_ms"] / args.steps, "total_gpu_ms_per_step": st["total_ms"] / args.steps,

@@ -1,0 +1,172 @@
+// cli_main.cpp -- `compseed_amd_cli`: the CompSeed command line for the seeding path, on MI355X.
+//
+//   compseed_amd_cli [options] <FM-index prefix> <reordered reads>
+//
+// Same positional arguments and the same seeding flags as `CompSeed` / `bwamem` (main.cpp:146-200, 233-330):
+// -t -k -r -y -c -s -K.  Everything downstream of seeding (chaining, banded SW, SAM) is out of scope, so instead of SAM
+// the program writes the seeds (--dump-seeds FILE) and prints the reference's exit counters (display_profile,
+// main.cpp:203-214).  Flags of the stages that are not here are accepted and ignored so existing command lines run.
+// Input: one read per line (input_reorder_reads, main.cpp:36-58) or FASTQ when the first byte is '@' (main.cpp:399-406).
+// Chunking follows main.cpp:54,437: a chunk ends at the first even read count that reaches -K bases
+// (default 10,000,000 x n_threads).  Chunks are split into contiguous read ranges, one per GPU (--gpus N, default all).
+#include "../../include/compseed_amd.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct Chunk { std::vector<uint8_t> bases; std::vector<uint64_t> off; };
+
+static bool read_chunk(FILE *fp, bool fastq, long chunk_bases, Chunk &c)
+{
+	c.bases.clear(); c.off.assign(1, 0);
+	static std::vector<char> line(1 << 17);
+	long size = 0;
+	for (;;) {
+		if (!fgets(line.data(), (int)line.size(), fp)) break;
+		if (fastq) { // 4-line records: @name / sequence / + / quality
+			if (line[0] != '@') break;
+			if (!fgets(line.data(), (int)line.size(), fp)) break;
+		}
+		size_t l = strlen(line.data());
+		while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) --l;
+		c.bases.insert(c.bases.end(), line.begin(), line.begin() + l);
+		c.off.push_back(c.bases.size());
+		size += (long)l;
+		if (fastq) { char tmp[1 << 16]; if (!fgets(tmp, sizeof tmp, fp) || !fgets(tmp, sizeof tmp, fp)) break; }
+		if (size >= chunk_bases && ((c.off.size() - 1) & 1) == 0) break; // main.cpp:54
+	}
+	return c.off.size() > 1;
+}
+
+static void usage()
+{
+	fprintf(stderr,
+	        "Usage: compseed_amd_cli [options] <FM-index> <Reordered Reads>\n\n"
+	        "Seeding options (same meaning as CompSeed / bwamem):\n"
+	        "       -t INT        host threads of the reference; sets the default chunk size (-K) [1]\n"
+	        "       -k INT        minimum seed length [19]\n"
+	        "       -r FLOAT      look for internal seeds inside a seed longer than {-k} * FLOAT [1.5]\n"
+	        "       -y INT        seed occurrence for the 3rd round seeding [20]\n"
+	        "       -c INT        skip seeds with more than INT occurrences [500]\n"
+	        "       -s INT        re-seed only SMEMs with at most INT occurrences [10]\n"
+	        "       -K INT        process INT input bases in each batch [10000000 x -t]\n"
+	        "GPU / output options:\n"
+	        "       --gpus INT    number of MI355X to shard each batch over [all visible]\n"
+	        "       --no-sal      stop after SMEM collection (no suffix-array lookup)\n"
+	        "       --dump-seeds FILE   write `M read beg end x0 x1 x2` and `S read qbeg len rbeg` lines\n"
+	        "Other CompSeed flags (-w -d -D -W -m -S -P -A -B -O -E -L -U -x -p -R -H -o -j -5 -q -v -T -h -a -C -V -Y -M -I)\n"
+	        "belong to stages behind seeding; they are accepted and ignored.\n");
+}
+
+int main(int argc, char **argv)
+{
+	cs_params_t par; cs_params_default(&par);
+	int n_threads = 1, n_gpus = -1; long fixed_chunk = 0; const char *dump = nullptr;
+	std::vector<const char *> pos;
+	for (int i = 1; i < argc; ++i) {
+		std::string a = argv[i];
+		auto need = [&]() -> const char * { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
+		if (a == "-k") par.min_seed_len = atoi(need());
+		else if (a == "-r") par.split_factor = (float)atof(need());
+		else if (a == "-y") par.max_mem_intv = (uint64_t)atol(need());
+		else if (a == "-c") par.max_occ = atoi(need());
+		else if (a == "-s") par.split_width = atoi(need());
+		else if (a == "-t") { n_threads = atoi(need()); if (n_threads < 1) n_threads = 1; }
+		else if (a == "-K") fixed_chunk = atol(need());
+		else if (a == "--gpus") n_gpus = atoi(need());
+		else if (a == "--no-sal") par.want_sal = 0;
+		else if (a == "--dump-seeds") dump = need();
+		else if (a.size() == 2 && a[0] == '-' && strchr("wdDWmABOELUxRHovThI", a[1])) (void)need(); // flags with a value, other stages
+		else if (a.size() == 2 && a[0] == '-' && strchr("SPpj5qaCVYM1", a[1])) {}                    // switches, other stages
+		else if (a[0] == '-' && a.size() > 1) { fprintf(stderr, "[E::main] unknown option %s\n", a.c_str()); usage(); return 1; }
+		else pos.push_back(argv[i]);
+	}
+	if (pos.size() < 2) { usage(); return 1; }
+	if (par.min_seed_len < 1) { fprintf(stderr, "[E::main] -k must be positive\n"); return 1; }
+
+	cs_index_t *idx = nullptr;
+	if (cs_index_load(pos[0], &idx)) { fprintf(stderr, "[E::main] fail to locate the index files: %s\n", cs_last_error()); return 1; }
+	cs_index_view_t view; cs_index_view(idx, &view);
+	int ndev = 0;
+	if (cs_device_count(&ndev) || ndev < 1) { fprintf(stderr, "[E::main] no MI355X visible: %s\n", cs_last_error()); return 1; }
+	if (n_gpus < 1 || n_gpus > ndev) n_gpus = ndev;
+	std::vector<cs_engine_t *> eng((size_t)n_gpus, nullptr);
+	for (int g = 0; g < n_gpus; ++g)
+		if (cs_engine_create(&view, g, &eng[g])) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); return 1; }
+
+	FILE *fp = fopen(pos[1], "r");
+	if (!fp) { fprintf(stderr, "[E::main] fail to open file `%s'.\n", pos[1]); return 1; }
+	int first = fgetc(fp); ungetc(first, fp);
+	bool fastq = first == '@';
+	FILE *fo = dump ? fopen(dump, "w") : nullptr;
+	if (dump && !fo) { fprintf(stderr, "[E::main] cannot write %s\n", dump); return 1; }
+	long chunk_bases = fixed_chunk > 0 ? fixed_chunk : 10000000L * n_threads; // main.cpp:437
+
+	Chunk c; uint64_t n_processed = 0;
+	while (read_chunk(fp, fastq, chunk_bases, c)) {
+		int64_t n = (int64_t)c.off.size() - 1;
+		for (int64_t r = 0; r < n; ++r)
+			if (c.off[r + 1] - c.off[r] >= 65535) { // MAX_READ_LEN, main.cpp:83-86 (the reference aborts here)
+				fprintf(stderr, "[E::process] Read length of %ld exceeds the limit %d\n", (long)(c.off[r + 1] - c.off[r]), 65535);
+				return 1;
+			}
+		// contiguous read ranges per GPU keep neighbouring (overlapping) reads together
+		std::vector<cs_result_t> res((size_t)n_gpus);
+		std::vector<int> rc((size_t)n_gpus, 0);
+		std::vector<std::string> err((size_t)n_gpus);
+		std::vector<std::vector<uint64_t>> loff((size_t)n_gpus);
+		std::vector<std::thread> th;
+		for (int g = 0; g < n_gpus; ++g) {
+			int64_t r0 = n * g / n_gpus, r1 = n * (g + 1) / n_gpus;
+			loff[g].resize((size_t)(r1 - r0) + 1);
+			for (int64_t r = r0; r <= r1; ++r) loff[g][(size_t)(r - r0)] = c.off[r] - c.off[r0];
+			th.emplace_back([&, g, r0, r1]() {
+				rc[g] = cs_engine_seed_batch(eng[g], &par, r1 - r0, c.bases.data() + c.off[r0], loff[g].data(), &res[g]);
+				if (rc[g]) err[g] = cs_last_error();
+			});
+		}
+		for (auto &t : th) t.join();
+		for (int g = 0; g < n_gpus; ++g) if (rc[g]) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, err[g].c_str()); return 1; }
+		if (fo)
+			for (int g = 0; g < n_gpus; ++g) {
+				int64_t r0 = n * g / n_gpus;
+				const cs_result_t &R = res[g];
+				for (int64_t r = 0; r < R.n_reads; ++r) {
+					uint64_t id = n_processed + (uint64_t)(r0 + r) + 1; // read names are running integers from 1 (main.cpp:47)
+					for (uint64_t m = R.mem_off[r]; m < R.mem_off[r + 1]; ++m)
+						fprintf(fo, "M\t%lu\t%u\t%u\t%lu\t%lu\t%lu\n", (unsigned long)id, (unsigned)(R.mems[m].info >> 32), (unsigned)R.mems[m].info,
+						        (unsigned long)R.mems[m].x0, (unsigned long)R.mems[m].x1, (unsigned long)R.mems[m].x2);
+					if (R.seed_off)
+						for (uint64_t s = R.seed_off[r]; s < R.seed_off[r + 1]; ++s)
+							fprintf(fo, "S\t%lu\t%d\t%d\t%ld\n", (unsigned long)id, R.seeds[s].qbeg, R.seeds[s].len, (long)R.seeds[s].rbeg);
+				}
+			}
+		n_processed += (uint64_t)n;
+	}
+	fclose(fp);
+	if (fo) fclose(fo);
+
+	cs_stats_t tot; memset(&tot, 0, sizeof tot);
+	for (int g = 0; g < n_gpus; ++g) {
+		cs_stats_t st; cs_engine_stats(eng[g], &st);
+		tot.reads += st.reads; tot.bwt_queries += st.bwt_queries; tot.bwt_calls += st.bwt_calls; tot.sal_queries += st.sal_queries;
+		tot.sal_calls += st.sal_calls; tot.mems += st.mems; tot.seeds += st.seeds;
+		tot.seed_kernel_ms = st.seed_kernel_ms > tot.seed_kernel_ms ? st.seed_kernel_ms : tot.seed_kernel_ms;
+		tot.sal_kernel_ms = st.sal_kernel_ms > tot.sal_kernel_ms ? st.sal_kernel_ms : tot.sal_kernel_ms;
+		tot.total_ms = st.total_ms > tot.total_ms ? st.total_ms : tot.total_ms;
+		cs_engine_destroy(eng[g]);
+	}
+	cs_index_free(idx);
+	// display_profile, main.cpp:203-214
+	fprintf(stderr, "BWT-extend:  %lu queries, %lu calls, %.2f %% hit in SST\n", (unsigned long)tot.bwt_queries, (unsigned long)tot.bwt_calls,
+	        tot.bwt_queries ? 100.0 * (double)(tot.bwt_queries - tot.bwt_calls) / (double)tot.bwt_queries : 0.0);
+	fprintf(stderr, "SA Lookup:   %lu queries, %lu calls, %.2f %% merged\n", (unsigned long)tot.sal_queries, (unsigned long)tot.sal_calls,
+	        tot.sal_queries ? 100.0 * (double)(tot.sal_queries - tot.sal_calls) / (double)tot.sal_queries : 0.0);
+	fprintf(stderr, "Wall time:   BWT %.2f SAL %.2f seconds on %d GPU(s); %lu reads, %lu mems, %lu seeds\n", tot.seed_kernel_ms / 1e3,
+	        tot.sal_kernel_ms / 1e3, n_gpus, (unsigned long)tot.reads, (unsigned long)tot.mems, (unsigned long)tot.seeds);
+	return 0;
+}

@@ -168,3 +168,27 @@ def test_both_smem_kernels_match_golden(monkeypatch, mode):
         bases, off = _data.load_reads(name)
         _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
     e.close(); ix.close()
+
+
+def test_cli_dump_matches_golden(tmp_path):
+    """the CompSeed-compatible command line: same flags, seed dump identical to the reference golden"""
+    import subprocess
+    import compseed_amd as ca
+    cli = os.path.join(os.path.dirname(ca.lib_path()), "compseed_amd_cli")
+    out = tmp_path / "seeds.txt"
+    r = subprocess.run([cli, "-t", "2", "-k", "14", "-K", "3000", "-w", "100", "-M", "--gpus", "1", "--dump-seeds", str(out), _data.PREFIX,
+                        os.path.join(_data.GOLD, "ragged.txt")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    z, _ = _data.load_golden("ragged", "k14")
+    mems, seeds = [], []
+    for ln in open(out):
+        f = ln.split("\t")
+        if f[0] == "M":
+            mems.append((int(f[1]) - 1, (int(f[2]) << 32) | int(f[3]), int(f[4]), int(f[5]), int(f[6])))
+        else:
+            seeds.append((int(f[1]) - 1, int(f[2]), int(f[3]), int(f[4])))
+    gm = z["mems"]; rd = np.repeat(np.arange(z["mem_off"].size - 1), np.diff(z["mem_off"].astype(np.int64)))
+    assert mems == [(int(rd[i]), int(gm[i, 3]), int(gm[i, 0]), int(gm[i, 1]), int(gm[i, 2])) for i in range(gm.shape[0])]
+    rs = np.repeat(np.arange(z["seed_off"].size - 1), np.diff(z["seed_off"].astype(np.int64)))
+    assert seeds == [(int(rs[i]), int(z["seed_qbeg"][i]), int(z["seed_len"][i]), int(z["seed_rbeg"][i])) for i in range(rs.size)]
+    assert "BWT-extend:" in r.stderr and "SA Lookup:" in r.stderr
