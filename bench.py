@@ -35,8 +35,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("CS_BENCH_GENOME_MBP", "1000")),
-                    help="synthetic genome size (hg19 = 3100; needs the 64-bit index builder)")
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("CS_BENCH_GENOME_MBP", "3100")),
+                    help="synthetic genome size in Mbp (3100 = hg19 scale)")
     ap.add_argument("--reads", type=int, default=int(os.environ.get("CS_BENCH_READS", "10000000")), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-sal", action="store_true")
@@ -70,6 +70,7 @@ def main():
     g_host = G.cpu().numpy()
     torch.cuda.synchronize()
     t1 = time.time()
+    torch.cuda.empty_cache()
     ix = ca.Index.build(g_host, local)
     t2 = time.time()
     eng = ca.Engine(ix, local)

@@ -189,6 +189,8 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, e->device));
 	e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	const bool verbose = getenv("CS_VERBOSE") != nullptr;
+	if (verbose) { fprintf(stderr, "[cs_engine] creating engine on device %d, seq_len %llu\n", e->device, (unsigned long long)v->seq_len); fflush(stderr); }
 	HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 	for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
 
@@ -232,6 +234,7 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	ix.sa_mask = (uint32_t)(v->sa_intv - 1);
 	ix.sa_shift = (uint32_t)__builtin_ctzll(v->sa_intv);
 
+	if (verbose) { fprintf(stderr, "[cs_engine] index uploaded and re-laid out\n"); fflush(stderr); }
 	// full suffix array in HBM (4 B/row below 2^32 rows, else 8 B/row): 50 GB for hg19 of the 288 GB on board
 	ix.fsa32 = nullptr; ix.fsa64 = nullptr;
 	const char *fs = getenv("CS_FULL_SA");
@@ -239,7 +242,7 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		uint64_t rows = v->seq_len + 1;
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		bool small = rows < 0xffffffffull;
+		bool small = rows < 0xffffffffull && !getenv("CS_FSA64"); // CS_FSA64: force 8-byte entries (tests)
 		size_t need = (size_t)rows * (small ? 4 : 8);
 		if (need + ((size_t)8 << 30) < free_b) {
 			unsigned grid = (unsigned)((v->n_sa + 255) / 256);
@@ -257,6 +260,7 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		}
 	}
 
+	if (verbose) { fprintf(stderr, "[cs_engine] full suffix array: %s\n", ix.fsa32 ? "4-byte" : ix.fsa64 ? "8-byte" : "off"); fflush(stderr); }
 	if (const char *s = getenv("CS_LEP_LDS")) { int v = atoi(s); g_lep_lds = (v == 10 || v == 13) ? v : 20; }
 	if (const char *s = getenv("CS_MEM_CAP")) { int c = atoi(s); if (c >= 1 && c <= 4096) e->cap = (uint32_t)c; }
 	if (const char *s = getenv("CS_MAX_RAW_MB")) { long m = atol(s); if (m >= 1) e->max_raw_bytes = (size_t)m << 20; }
