@@ -1,0 +1,35 @@
+#!/bin/bash
+# tools/profile_round.sh <tag> -- rocprofv3 kernel-trace summary (+ optional FETCH_SIZE pass) of the default bench command.
+# Run on the GPU box:  gpurun -- 'tools/profile_round.sh r01_v2'
+# Writes small summaries to gpurun_out/ (copy the ones to be judged into profiles/).
+tag=${1:-rXX}
+R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp; ulimit -c 0
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $R/gpurun_out/${tag}_bench_profiled.json 2> /tmp/prof_$tag.err
+python3 - "$tag" <<'PY'
+import csv, glob, sys, os
+tag = sys.argv[1]; R = os.environ["GRAFT_REPO_ROOT"]
+f = glob.glob("/tmp/prof_%s/**/*kernel_stats.csv" % tag, recursive=True)[0]
+rows = list(csv.reader(open(f)))
+keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ("csd::", "anonymous namespace", "rocprim", "max_len", "collect_overflow", "patch_counts", "sort_compact"))]
+with open(os.path.join(R, "gpurun_out", tag + "_kernel_stats.csv"), "w", newline="") as o:
+    w = csv.writer(o)
+    for r in keep:
+        r = list(r); r[0] = r[0][:110]; w.writerow(r)
+PY
+if [ -n "$2" ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --check-reads 1000 > /tmp/pmc_$tag.json 2> /tmp/pmc_$tag.err
+  python3 - "$tag" <<'PY'
+import csv, glob, sys, os, collections, json
+tag = sys.argv[1]; R = os.environ["GRAFT_REPO_ROOT"]
+agg = collections.defaultdict(float); n = collections.Counter()
+for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % tag, recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        name = "fwd_kernel" if "fwd_kernel" in k else "bwd_all_kernel" if "bwd_all" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
+        if name and r["Counter_Name"] == "FETCH_SIZE":
+            agg[name] += float(r["Counter_Value"]); n[name] += 1
+out = {k: {"FETCH_SIZE_KiB_sum": v, "dispatches": n[k]} for k, v in agg.items()}
+json.dump(out, open(os.path.join(R, "gpurun_out", tag + "_pmc_fetch.json"), "w"), indent=1)
+print(json.dumps(out))
+PY
+fi
