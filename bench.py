@@ -47,21 +47,18 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log("WORLD_SIZE %d != --gpus %d, using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the seeding engine has no CPU path")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     import compseed_amd as ca
+    from compseed_amd.sharding import Dist
     import synth
+    D = Dist("nccl")                      # RCCL; used for the barrier and the max-over-ranks clock only
+    rank, world = D.rank, D.world
+    if world != args.gpus and world > 1:
+        log("WORLD_SIZE %d != --gpus %d, using WORLD_SIZE" % (world, args.gpus))
 
     # ---- workload: synthetic genome (same on every rank), index built on this rank's GPU, reads of this rank's share
     t0 = time.time()
@@ -89,25 +86,15 @@ def main():
     def step():
         return eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), args.reads, n_bases, par)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         res = step()
     eng.reset_stats()
-    barrier()
+    D.barrier()
     ts = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-    barrier()
-    elapsed = time.perf_counter() - ts
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - ts)
     st = eng.stats()
 
     total_reads = args.reads * world * args.steps
@@ -187,9 +174,7 @@ def main():
                                    "sample": "first %d reads of rank 0's batch, oracle/cs_oracle.c in CompSeed mode (SST per 512 reads), %d threads, %.1f s"
                                              % (ncpu, cores, dt)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
     eng.close(); ix.close()
 
 
