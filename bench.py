@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("CS_BENCH_READS", "10000000")), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-sal", action="store_true")
+    ap.add_argument("--sst", type=int, default=int(os.environ.get("CS_BENCH_SST", "1")), help="on-device SST memo (1 = on, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-for-bit against the oracle after the timed region")
     ap.add_argument("-k", type=int, default=19); ap.add_argument("-r", type=float, default=1.5)
@@ -81,7 +82,7 @@ def main():
     if rank == 0:
         log("genome %.0f Mbp: generate %.1fs, index build %.1fs (seq_len %d), upload %.1fs, reads %d x %d in %.1fs" %
             (args.genome_mbp, t1 - t0, t2 - t1, ix.view.seq_len, t3 - t2, args.reads, args.read_len, time.time() - t3))
-    par = ca.Params(k=args.k, r=args.r, s=args.s, c=args.c, y=args.y, want_sal=0 if args.no_sal else 1)
+    par = ca.Params(k=args.k, r=args.r, s=args.s, c=args.c, y=args.y, want_sal=0 if args.no_sal else 1, sst_mode=args.sst)
 
     def step():
         return eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), args.reads, n_bases, par)
@@ -156,6 +157,8 @@ def main():
                            "kernel_ms_per_launch": kern_ms, "launches": launches,
                            "algorithmic_bytes_per_read": per_read, "uncached_bytes_per_read": per_read_unc,
                            "bwt_extend_queries_per_read": st["bwt_queries"] / (args.reads * args.steps),
+                           "device_sst_hit_rate": 1.0 - st["bwt_calls"] / max(1, st["bwt_queries"]),
+                           "reference_sst_hit_rate": 1.0 - ws["bwt_calls"] / max(1, ws["bwt_queries"]),
                            "sal_ms_per_step": st["sal_kernel_ms"] / args.steps, "total_gpu_ms_per_step": st["total_ms"] / args.steps,
                            "overflow_reads_per_step": st["overflow_reads"] / args.steps,
                            "overflow_pass_ms_per_step": st["overflow_kernel_ms"] / args.steps}

@@ -33,7 +33,7 @@ class Params(C.Structure):
     _fields_ = [("min_seed_len", C.c_int32), ("split_factor", C.c_float), ("split_width", C.c_int32),
                 ("max_occ", C.c_int32), ("max_mem_intv", C.c_uint64), ("want_sal", C.c_int32), ("sst_mode", C.c_int32)]
 
-    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=0):
+    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=1):
         super().__init__(k, r, s, c, y, want_sal, sst_mode)
 
 

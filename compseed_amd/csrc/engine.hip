@@ -43,7 +43,7 @@ extern "C" void cs_params_default(cs_params_t *p)
 {
 	if (!p) return;
 	p->min_seed_len = 19; p->split_factor = 1.5f; p->split_width = 10; p->max_occ = 500; p->max_mem_intv = 20;
-	p->want_sal = 1; p->sst_mode = 0;
+	p->want_sal = 1; p->sst_mode = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ grow-only buffers
@@ -439,7 +439,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.split_width = (uint32_t)par->split_width; A.max_mem_intv = par->max_mem_intv;
 	A.bq = e->d_bq.p;
 	A.lep = e->d_lep.p; A.lep_stride = stride;
-	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7;
+	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode;
 	A.fq_cap = fq_cap; A.n_f_next = C + 1;
 
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;
@@ -482,7 +482,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	HIP_TRY(hipStreamSynchronize(s));
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 	e->st.seed_kernel_launches++;
-	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8];
+	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8] - H[9]; // calls = queries not answered by the on-device SST
 	*n_ovf_out = H[6];
 	return CS_OK;
 }

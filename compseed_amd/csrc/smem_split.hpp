@@ -58,6 +58,8 @@ struct SplitArgs {
 	unsigned long long *task_ctr;
 	unsigned long long *n_queries;
 	unsigned long long *err;                          // sticky: a queue overflowed
+	unsigned long long *n_sst_hits;                   // bwt_extend queries answered by the on-device SST
+	int32_t   sst;                                    // cs_params_t.sst_mode
 };
 
 __device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const Intv &v, uint32_t beg, uint32_t end)
@@ -87,6 +89,38 @@ __device__ __forceinline__ uint64_t emit_smem(const SplitArgs &A, uint32_t r, ui
 		return ftask_pack(r, (uint32_t)(beg + (int)end) >> 1, (uint32_t)v.x2 + 1, TK_ROUND2);
 	return FTASK_NONE;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// On-device SST (mapping/SST.h on the CPU): a transparent memo of bwt_extend, resident in LDS.
+//
+// The CPU SST is two tries (forward / backward) of bi-intervals keyed by the path of bases, reset every 512 reads.  A
+// bi-interval is a function of the STRING alone, whichever direction it was reached from, so on the device one table
+// keyed by the string serves both directions: entry (len, code) holds the interval of the string whose 2-bit packed
+// bases are `code`.  It covers every string of up to SST_K bases (sum 4^d = 1364 entries x 16 B = 21.8 KB per
+// workgroup, so occupancy is untouched), starts empty in every workgroup and is filled lazily: a miss costs exactly the
+// bwt_extend it would have cost anyway and publishes the child; a hit answers from LDS with no HBM/L2 round trip.  Racing
+// writers store identical values (the memoised function is pure), entries are single 16-byte LDS accesses.  Deeper
+// strings are not cached: beyond ~12 bases every extension is a distinct random line whether a trie node or an Occ
+// block answers it, so only an LDS-resident level set saves anything.
+constexpr int SST_K = 5;
+constexpr int SST_ENTRIES = 4 + 16 + 64 + 256 + 1024;
+__device__ __forceinline__ int sst_index(int len, uint32_t code) // len in 1..SST_K
+{
+	return ((1 << (2 * len)) - 4) / 3 + (int)code; // 4 + 16 + ... + 4^(len-1) entries precede length `len`
+}
+__device__ __forceinline__ void sst_clear(uint4 *sst)
+{
+	for (int t = threadIdx.x; t < SST_ENTRIES; t += blockDim.x) sst[t] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+	__syncthreads();
+}
+__device__ __forceinline__ bool sst_get(const uint4 *sst, int len, uint32_t code, Intv &v)
+{
+	uint4 e = sst[sst_index(len, code)];
+	if (e.w == 0xffffffffu) return false; // empty: a stored entry keeps its top 16 bits (the unused query end) zero
+	uint32_t end; unpack_lep(e, v, end);
+	return true;
+}
+__device__ __forceinline__ void sst_put(uint4 *sst, int len, uint32_t code, const Intv &v) { sst[sst_index(len, code)] = pack_lep(v, 0); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // initial tasks: round-1 call at the first unambiguous base, and the round-3 chain (bwamem.c:226, 253)
@@ -194,8 +228,12 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 	Intv ik = {0, 0, 0};
 	BaseReader<1> rd;
 	uint4 *lep = nullptr;
-	unsigned long long my_q = 0;
+	unsigned long long my_q = 0, my_hits = 0;
 	WavePool P = {0, 0, false};
+	__shared__ uint4 sst[SST_ENTRIES];
+	sst_clear(sst);
+	const bool use_sst = A.sst != 0;
+	int slen = 0; uint32_t scode = 0; // the string matched so far, while it is short enough for the SST
 
 	for (;;) {
 		uint64_t t_id = 0;
@@ -211,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 					rd.start(A.seq, rb, x);
 					lep = A.lep + tslot * A.lep_stride; n = 0;
 					if (kind == TK_ROUND3) while (x < len && rd.at(x) > 3) ++x; // first start (bwamem.c:255-256)
-					if (x < len) { ik = set_intv(ix, (int)rd.at(x)); i = x + 1; active = true; }
+					if (x < len) { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; active = true; }
 				}
 			}
 		}
@@ -220,7 +258,15 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 		// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
 		uint32_t b = i < len ? rd.at(i) : 4u;
 		Intv y = ik;
-		if (b <= 3) { y = extend1<false>(ix, ik, 3 - (int)b); ++my_q; }
+		bool cached = false, cacheable = use_sst && b <= 3 && slen < SST_K;
+		uint32_t ccode = scode << 2 | b;                    // the string extended by read base b
+		if (cacheable) cached = sst_get(sst, slen + 1, ccode, y);
+		if (b <= 3) {
+			++my_q;
+			if (cached) ++my_hits;
+			else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, slen + 1, ccode, y); }
+			scode = ccode; ++slen;                          // slen keeps counting; only values < SST_K are looked at
+		}
 
 		if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
 			if (b <= 3 && !(y.x2 < A.max_mem_intv && i - x >= A.min_seed_len)) { ik = y; ++i; continue; }
@@ -229,7 +275,8 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 			x = i + 1; // restart behind the seed / the ambiguous base
 			while (x < len && rd.at(x) > 3) ++x;
 			if (x >= len) { active = false; continue; }
-			ik = set_intv(ix, (int)rd.at(x)); i = x + 1;
+			scode = rd.at(x); slen = 1;
+			ik = set_intv(ix, (int)scode); i = x + 1;
 			continue;
 		}
 		// ---- forward pass of an SMEM call, bwt.c:303-320
@@ -244,6 +291,7 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 		active = false;
 	}
 	atomicAdd(A.n_queries, my_q);
+	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
 }
 
 // the call that follows a finished round-1 call: next pivot = end of the longest forward match, ambiguous bases skipped
@@ -257,8 +305,10 @@ __device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r,
 // ------------------------------------------------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
-                                               unsigned long long &my_q)
+                                               unsigned long long &my_q, unsigned long long &my_hits, uint4 *sst)
 {
+	const bool use_sst = A.sst != 0;
+	int slen = SST_K; uint32_t scode = 0; // this lane's match as a string, while it is short enough for the SST
 	constexpr uint32_t MYCLS = G == 16 ? 0u : G == 32 ? 1u : 2u;
 	const DevIndex &ix = A.ix;
 	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, gbase = lane - gl; // group = G consecutive lanes of a wave
@@ -308,8 +358,14 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				int x = bt.x, n = bt.n;
 				live = (int)gl < n;
 				if (live) unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend);
-				rd.start(A.seq, A.off[r], x - 1);
+				uint64_t rb = A.off[r];
+				rd.start(A.seq, rb, x - 1);
 				i = x - 1; nm = 0; last_start = 0;
+				slen = SST_K; scode = 0;
+				if (use_sst && live && (int)pend - x < SST_K) { // a short LEP: spell it, the SST is keyed by the string
+					slen = (int)pend - x;
+					for (int q = 0; q < slen; ++q) scode = scode << 2 | A.seq[rb + x + q];
+				}
 				active = true;
 			}
 		}
@@ -325,7 +381,15 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				end_call = true;
 			} else {
 				Intv y = e;
-				if (live) { y = extend1<true>(ix, e, (int)b); ++my_q; }
+				bool cacheable = use_sst && live && slen < SST_K, cached = false;
+				uint32_t ccode = b << (2 * slen) | scode;       // read base b in front of the string
+				if (cacheable) cached = sst_get(sst, slen + 1, ccode, y);
+				if (live) {
+					++my_q;
+					if (cached) ++my_hits;
+					else { y = extend1<true>(ix, e, (int)b); if (cacheable) sst_put(sst, slen + 1, ccode, y); }
+					if (slen < SST_K) { scode = ccode; ++slen; }
+				}
 				bool stop = live && y.x2 < min_intv, cand = live && !stop;
 				uint64_t cand_m = __ballot(cand) & gmask;
 				// bwt.c:328-336: the first live match is an SMEM if it stops here (nothing longer survived) and is not contained
@@ -427,17 +491,20 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 4) void bwd_all_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
 	WaveOut O = {0, 0};
-	unsigned long long my_q = 0;
+	unsigned long long my_q = 0, my_hits = 0;
+	__shared__ uint4 sst[SST_ENTRIES];
+	sst_clear(sst);
 	const uint32_t role = blockIdx.x & 7u, first = role < 5 ? 0u : role - 4u; // 5/8 of the workgroups start on the <=16 class
 	for (uint32_t k = 0; k < 4; ++k) {
 		uint32_t c = (first + k) & 3u;
-		if (c == 0) bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q);
-		else if (c == 1) bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q);
-		else if (c == 2) bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q);
+		if (c == 0) bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
+		else if (c == 1) bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
+		else if (c == 2) bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
 		else bwd_wide_run(A, bq, n_tasks, ctrs + 3, O, my_q);
 	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
+	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
 }
 
 // one lane, list in HBM, compacted in place (reference form of the sweep; kept for A/B tests of the wide path)

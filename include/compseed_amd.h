@@ -59,7 +59,8 @@ typedef struct {
 	int32_t  max_occ;        /* [-c] 500  */
 	uint64_t max_mem_intv;   /* [-y] 20   */
 	int32_t  want_sal;       /* 1: also produce seeds (SAL block), 0: mems only */
-	int32_t  sst_mode;       /* 0: on-device SST cache off, 1: on (results identical; only speed/counters differ) */
+	int32_t  sst_mode;       /* 1: on-device SST (LDS-resident memo of bwt_extend, mapping/SST.h) on [default], 0: off.
+	                          * Results are identical either way; only speed and the bwt_calls counter differ */
 } cs_params_t;
 
 /* CSR result of one batch.  Read r owns mems[mem_off[r] .. mem_off[r+1]) sorted by info (comp_seed.cpp:2301) and

@@ -192,3 +192,21 @@ def test_cli_dump_matches_golden(tmp_path):
     rs = np.repeat(np.arange(z["seed_off"].size - 1), np.diff(z["seed_off"].astype(np.int64)))
     assert seeds == [(int(rs[i]), int(z["seed_qbeg"][i]), int(z["seed_len"][i]), int(z["seed_rbeg"][i])) for i in range(rs.size)]
     assert "BWT-extend:" in r.stderr and "SA Lookup:" in r.stderr
+
+
+def test_device_sst_is_transparent(eng):
+    """sst_mode switches the LDS-resident memo of bwt_extend on and off: identical seeds, fewer real calls when on
+    (the cache only memoises a pure function -- SURVEY Appendix B.1 -- so the A/B is a built-in test)"""
+    import compseed_amd as ca
+    for name, pname in (("main100", "default"), ("ragged", "k14"), ("repeat100", "c50s20"), ("sorted150", "r1.0")):
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        stats = {}
+        for mode in (0, 1):
+            eng.reset_stats()
+            res = eng.seed_batch(bases, off, ca.Params(sst_mode=mode, **kw))
+            _check_against_golden(res, z)
+            stats[mode] = eng.stats()
+        assert stats[0]["bwt_queries"] == stats[1]["bwt_queries"] == int(z["counters"][3])
+        assert stats[0]["bwt_calls"] == stats[0]["bwt_queries"]
+        assert stats[1]["bwt_calls"] < stats[1]["bwt_queries"]
