@@ -84,7 +84,8 @@ template <typename T> struct PinBuf {
 struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr; // stream2: the independent round-3 chains, filling the other launches' tails
+	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
@@ -101,7 +102,7 @@ struct cs_engine {
 	PinBuf<uint64_t> h_mem_off, h_seed_off; PinBuf<OutMem> h_mems; PinBuf<OutSeed> h_seeds;
 	PinBuf<unsigned long long> h_ctr;
 	// split (forward / cooperative backward) SMEM path
-	DevBuf<uint64_t> d_fqA, d_fqB; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
+	DevBuf<uint64_t> d_fqA, d_fqB, d_fqR; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
 	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
 	int smem_mode = 1;          // 1 = split kernels (default), 0 = fused one-lane-per-read kernel (CS_SMEM_MODE=fused)
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
@@ -193,6 +194,13 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	if (verbose) { fprintf(stderr, "[cs_engine] creating engine on device %d, seq_len %llu\n", e->device, (unsigned long long)v->seq_len); fflush(stderr); }
 	HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 	for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+	{
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
+		HIP_TRY(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_r3a, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_r3b, hipEventDisableTiming));
+	}
 
 	if (v->seq_len == 0 || v->seq_len != v->L2[4] || v->L2[0] != 0) return fail(CS_EINVAL, "index view: L2 / seq_len inconsistent");
 	if (v->seq_len >> 37) return fail(CS_ERANGE, "index longer than 2^37 symbols does not fit the packed LEP entries");
@@ -288,10 +296,13 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
-	e->d_fqA.release(); e->d_fqB.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
+	e->d_fqA.release(); e->d_fqB.release(); e->d_fqR.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
 	e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+	if (e->ev_r3a) (void)hipEventDestroy(e->ev_r3a);
+	if (e->ev_r3b) (void)hipEventDestroy(e->ev_r3b);
+	if (e->stream2) (void)hipStreamDestroy(e->stream2);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
 }
@@ -423,7 +434,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	const uint64_t fq_cap = (uint64_t)nb * 8 + 4096, ovf_cap = (uint64_t)nb * 4 + 65536;
 	uint64_t chunk = std::max<uint64_t>(4096, e->lep_arena_bytes / ((size_t)stride * sizeof(uint4)));
 	chunk = std::min<uint64_t>(chunk, fq_cap);
-	CS_TRY(e->d_fqA.reserve(fq_cap)); CS_TRY(e->d_fqB.reserve(fq_cap));
+	CS_TRY(e->d_fqA.reserve(fq_cap)); CS_TRY(e->d_fqB.reserve(fq_cap)); CS_TRY(e->d_fqR.reserve((size_t)nb + 1));
 	CS_TRY(e->d_bq.reserve(chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
 	CS_TRY(e->d_ovfrec.reserve(ovf_cap));
 	unsigned long long *C = e->d_sctr.p, *H = e->h_sctr.p; // [0] task ctr [1] next-queue length [2..5] backward queues [6] overflow mems [7] error [8] queries
@@ -445,18 +456,28 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;
 	A.fq = cur; A.n_f = 0; A.fq_next = nxt;
 	HIP_TRY(hipEventRecord(e->ev[0], s));
-	hipLaunchKernelGGL(init_tasks_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, A, cur);
-	uint64_t n_f = 2 * (uint64_t)nb;
+	hipLaunchKernelGGL(init_tasks_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, A, cur, e->d_fqR.p);
+	// Round 3 depends on nothing: it runs on a low-priority second stream and fills the tails of the launches below.
+	bool r3_async = A.max_mem_intv > 0;
+	if (r3_async) {
+		SplitArgs R = A;
+		R.fq = e->d_fqR.p; R.n_f = (uint64_t)nb; R.task_ctr = C + 10;
+		HIP_TRY(hipEventRecord(e->ev_r3a, s));
+		HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_r3a, 0));
+		unsigned gr = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, ((uint64_t)nb + 255) / 256);
+		hipLaunchKernelGGL((fwd_kernel<256>), dim3(gr), dim3(256), 0, e->stream2, R);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
+	}
+	uint64_t n_f = (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
 		A.fq_next = nxt;
 		for (uint64_t c0 = 0; c0 < n_f; ) {
-			// iteration 0: the second half of the queue holds the round-3 chains, which use no LEP list => one launch
 			uint64_t cn = std::min<uint64_t>(chunk, n_f - c0);
-			if (iter == 0) cn = c0 < (uint64_t)nb ? std::min<uint64_t>(chunk, (uint64_t)nb - c0) : n_f - c0;
 			A.fq = cur + c0; A.n_f = cn;
 			HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
-			bool r3_only = (iter == 0 && c0 >= (uint64_t)nb);
-			if (!r3_only) HIP_TRY(hipMemsetAsync(e->d_bq.p, 0xff, cn * sizeof(BTask), s)); // slots without a call stay "no class"
+			const bool r3_only = false;
+			HIP_TRY(hipMemsetAsync(e->d_bq.p, 0xff, cn * sizeof(BTask), s)); // slots without a call stay "no class"
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
 			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
 			HIP_TRY(hipGetLastError());
@@ -471,12 +492,13 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		}
 		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
-		if (H[7]) return 1;
+		if (H[7]) { (void)hipStreamSynchronize(e->stream2); return 1; }
 		n_f = H[1];
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
 		std::swap(cur, nxt);
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
+	if (r3_async) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
 	HIP_TRY(hipEventRecord(e->ev[1], s));
 	HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));

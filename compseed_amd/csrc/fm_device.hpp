@@ -164,8 +164,19 @@ __device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int 
 	uint64_t xa = IS_BACK ? ik.x0 : ik.x1, xb = IS_BACK ? ik.x1 : ik.x0;
 	uint64_t k = xa - 1, l = xa - 1 + ik.x2;
 	uint64_t rk = k - (k >= ix.primary), rl = l - (l >= ix.primary);
+	// Both rows usually fall into ONE block once the interval is small (bwt.c:194): then one line is requested, not two.
+	// The second load sits under the lane's predicate and is issued right behind the first, so when it is needed the two
+	// lines still travel together; nothing waits until the first use below.
+	const bool two = (rk >> 7) != (rl >> 7);
 	Block bk = load_block(ix, rk >> 7);
-	Block bl = load_block(ix, rl >> 7);
+	Block b2;
+	if (two) b2 = load_block(ix, rl >> 7);
+	// the select below must not be folded into the branch above (the compiler would then wait for the first block before
+	// issuing the second in order to copy it): hide the predicate behind an empty asm
+	uint32_t two_sel = two ? 1u : 0u;
+	asm volatile("" : "+v"(two_sel));
+	Block bl;
+	bl.h0 = two_sel ? b2.h0 : bk.h0; bl.h1 = two_sel ? b2.h1 : bk.h1; bl.lo = two_sel ? b2.lo : bk.lo; bl.hi = two_sel ? b2.hi : bk.hi;
 	uint32_t nk = (uint32_t)(rk & 127) + 1, nl = (uint32_t)(rl & 127) + 1, k1, k2, k3, l1, l2, l3;
 	count_cgt(bk, nk, k1, k2, k3);
 	count_cgt(bl, nl, l1, l2, l3);

@@ -124,15 +124,15 @@ __device__ __forceinline__ void sst_put(uint4 *sst, int len, uint32_t code, cons
 
 // ------------------------------------------------------------------------------------------------------------------
 // initial tasks: round-1 call at the first unambiguous base, and the round-3 chain (bwamem.c:226, 253)
-__global__ void init_tasks_kernel(const SplitArgs A, uint64_t *fq)
+__global__ void init_tasks_kernel(const SplitArgs A, uint64_t *fq, uint64_t *fq_r3)
 {
 	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= A.n_reads) return;
 	uint64_t b = A.off[r]; int len = (int)(A.off[r + 1] - b), x = 0;
 	while (x < len && A.seq[b + x] > 3) ++x;
-	// the round-1 calls fill the first half of the queue, the round-3 chains the second half (they need no LEP list)
+	// the round-3 chains get a queue of their own: they depend on nothing and run on a second stream (engine.hip)
 	fq[r] = x < len ? ftask_pack((uint32_t)r, (uint32_t)x, 1, TK_ROUND1) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
-	fq[A.n_reads + r] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+	fq_r3[r] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
 }
 
 // Task dispenser.  One returning atomic on a single word costs ~11 ns and the word saturates near 88 M dequeues/s
