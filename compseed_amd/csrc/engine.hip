@@ -218,10 +218,14 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	CS_TRY(e->d_sa.reserve((size_t)v->n_sa));
 	HIP_TRY(hipMemcpyAsync(e->d_sa.p, v->sa, (size_t)v->n_sa * 8, hipMemcpyHostToDevice, e->stream));
 	// one-time conversion of the 2-bit packed bases of every block into bit planes (fm_device.hpp)
-	hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, e->stream, e->d_bwt.p, n_blocks);
-	HIP_TRY(hipGetLastError());
 	CS_TRY(e->d_sctr.reserve(16));
 	CS_TRY(e->h_sctr.reserve(16));
+	HIP_TRY(hipMemsetAsync(e->d_sctr.p, 0, 16 * sizeof(unsigned long long), e->stream));
+	hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, e->stream, e->d_bwt.p, n_blocks, e->d_sctr.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_sctr.p, e->d_sctr.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	if (e->h_sctr.p[0]) return fail(CS_ERANGE, "a single base occurs 2^32 times or more: 32-bit Occ counts of the device layout overflow");
 	{
 		int nb = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fwd_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_fwd = std::min(nb, 8);
@@ -777,9 +781,9 @@ __global__ void random_block_chain_kernel(const DevIndex ix, uint32_t steps, uin
 {
 	uint64_t k = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
 	for (uint32_t i = 0; i < steps; ++i) {
-		uint64_t b = (k >> 11) % ix.n_blocks;
+		uint64_t b = (k >> 11) % (2 * ix.n_blocks); // 32-byte records
 		Block blk = load_block(ix, b);
-		k = k * 6364136223846793005ull + (blk.h0.x ^ blk.h1.y ^ blk.lo.z ^ blk.hi.w) + 1442695040888963407ull;
+		k = k * 6364136223846793005ull + (blk.cnt.x ^ blk.cnt.w ^ blk.pl.y ^ blk.pl.z) + 1442695040888963407ull;
 	}
 	if (k == 42) *sink = k;
 }

@@ -3,17 +3,17 @@
 // Replaces (integer-exact) the reference's bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_set_intv / bwt_occ /
 // bwt_invPsi / bwt_sa (FM_index/bwt.c:169-186, 189-220, 262-275, 107-129, 53-59, 86-96; bwt.h:82).
 //
-// Device layout of the Occ-sampled BWT.  The file layout (FM_index/bwt.h:73-80) is kept block for block -- block b
-// covers BWT rows 128b .. 128b+127 ($ removed) and is ONE 64-byte line -- but inside the line the 128 two-bit bases
-// are stored as two bit planes instead of sixteen packed bases per word (relayout_kernel converts once at upload):
-//     quad 0: count(A), count(C)   (u64 each, occurrences before the block)          unchanged
-//     quad 1: count(G), count(T)                                                      unchanged
-//     quad 2: low  bit of bases 0..127  (word w, bit j = base 32w + j)
-//     quad 3: high bit of bases 0..127
-// One lane owns one query, so a block is four global_load_dwordx4 of one line.  Counting the bases up to a row is then
-// 4 words x (3 logic + 3 masked v_bcnt_u32_b32) with a simple "first t bits" mask per word, about half the vector
-// instructions of counting in the packed format and no 256-entry LUT (bwt.c:42-51,165) -- the kernels are bound by
-// instruction issue as much as by HBM latency, so this matters.  A is derived from the number of bases taken.
+// Device layout of the Occ-sampled BWT (relayout_kernel converts the file layout once at upload, in place, same size).
+// The file (FM_index/bwt.h:73-80) samples Occ every 128 rows: 4 x u64 counts + 128 two-bit bases = one 64-byte line.
+// On the device every 64 rows get their own self-sufficient 32-byte record, two records per line:
+//     quad 0: count(A), count(C), count(G), count(T) before the record's first row   (u32 each)
+//     quad 1: low-bit plane of the 64 bases (2 words, word w bit j = base 32w + j), then the high-bit plane (2 words)
+// One lane owns one query.  An Occ lookup is then TWO global_load_dwordx4 of one half line (the memory pipeline
+// charges a fully divergent wave-instruction per lane, and the kernels were measured to be stalled on VMEM issue, so
+// halving the instructions per lookup matters more than the bytes), and counting the bases up to a row is 2 words x
+// (3 logic + 3 masked v_bcnt_u32_b32) with a "first t bits" mask per word; no 256-entry LUT (bwt.c:42-51,165).  A is
+// derived from the number of bases taken.  32-bit counts hold as long as no single base occurs 2^32 times in
+// forward + reverse text (checked at engine creation; hg19: 1.8e9).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,11 +21,13 @@
 namespace csd {
 
 constexpr uint64_t NONE64 = ~0ull;
+constexpr int OCC_SHIFT = 6;            // rows per record = 64
+constexpr uint32_t OCC_MASK = 63;
 
 struct DevIndex {
-	const uint4    *bwt;      // 64-byte blocks as 4 quads (bit-plane layout above)
+	const uint4    *bwt;      // 32-byte records (2 quads) of 64 rows each
 	const uint64_t *sa;       // sampled SA, sa[0] = -1
-	uint64_t primary, seq_len, n_sa, n_blocks;
+	uint64_t primary, seq_len, n_sa, n_blocks; // n_blocks = 128-row blocks of the file layout
 	uint64_t L2[5];
 	uint32_t sa_mask, sa_shift;
 	// full suffix array materialised in HBM at engine creation (one entry per BWT row, 4 or 8 bytes): SAL becomes ONE
@@ -38,40 +40,45 @@ struct Intv { uint64_t x0, x1, x2; };
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
 
-// file layout -> bit planes, in place, one thread per block (run once per engine)
-__global__ void relayout_kernel(uint4 *bwt, uint64_t n_blocks)
+// file layout -> device layout, in place, one thread per 128-row block of the file (run once per engine)
+__global__ void relayout_kernel(uint4 *bwt, uint64_t n_blocks, unsigned long long *overflow)
 {
 	uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= n_blocks) return;
-	uint4 q2 = bwt[b * 4 + 2], q3 = bwt[b * 4 + 3];
+	uint4 q0 = bwt[b * 4], q1 = bwt[b * 4 + 1], q2 = bwt[b * 4 + 2], q3 = bwt[b * 4 + 3];
 	const uint32_t w[8] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-	uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+	uint64_t h[4] = {u64_of(q0.x, q0.y), u64_of(q0.z, q0.w), u64_of(q1.x, q1.y), u64_of(q1.z, q1.w)};
+	uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, first64[4] = {0, 0, 0, 0};
 	for (int i = 0; i < 128; ++i) {
 		uint32_t code = (w[i >> 4] >> ((15 - (i & 15)) << 1)) & 3u; // bwt_B0, bwt.h:80
 		lo[i >> 5] |= (code & 1u) << (i & 31);
 		hi[i >> 5] |= (code >> 1) << (i & 31);
+		if (i < 64) ++first64[code];
 	}
-	bwt[b * 4 + 2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-	bwt[b * 4 + 3] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+	for (int c = 0; c < 4; ++c) if ((h[c] + first64[c]) >> 32) atomicAdd(overflow, 1ull);
+	bwt[b * 4]     = make_uint4((uint32_t)h[0], (uint32_t)h[1], (uint32_t)h[2], (uint32_t)h[3]);
+	bwt[b * 4 + 1] = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+	bwt[b * 4 + 2] = make_uint4((uint32_t)(h[0] + first64[0]), (uint32_t)(h[1] + first64[1]), (uint32_t)(h[2] + first64[2]), (uint32_t)(h[3] + first64[3]));
+	bwt[b * 4 + 3] = make_uint4(lo[2], lo[3], hi[2], hi[3]);
 }
 
-struct Block { uint4 h0, h1, lo, hi; };
+struct Block { uint4 cnt, pl; }; // counts A,C,G,T | lo0, lo1, hi0, hi1
 
-__device__ __forceinline__ Block load_block(const DevIndex &ix, uint64_t b)
+__device__ __forceinline__ Block load_block(const DevIndex &ix, uint64_t rec)
 {
-	const uint4 *p = ix.bwt + (b << 2);
+	const uint4 *p = ix.bwt + (rec << 1);
 	Block k;
-	k.h0 = p[0]; k.h1 = p[1]; k.lo = p[2]; k.hi = p[3];
+	k.cnt = p[0]; k.pl = p[1];
 	return k;
 }
 
-// occurrences of C, G, T among the first `nb` (1..128) bases of a block
+// occurrences of C, G, T among the first `nb` (1..64) bases of a record
 __device__ __forceinline__ void count_cgt(const Block &k, uint32_t nb, uint32_t &c1, uint32_t &c2, uint32_t &c3)
 {
-	const uint32_t L[4] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w}, H[4] = {k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+	const uint32_t L[2] = {k.pl.x, k.pl.y}, H[2] = {k.pl.z, k.pl.w};
 	c1 = c2 = c3 = 0;
 #pragma unroll
-	for (int w = 0; w < 4; ++w) {
+	for (int w = 0; w < 2; ++w) {
 		int t = (int)nb - 32 * w;                                 // bases wanted from this word
 		uint32_t m = t >= 32 ? 0xffffffffu : (t <= 0 ? 0u : ((1u << t) - 1u));
 		uint32_t lo = L[w] & m, hi = H[w] & m;
@@ -84,12 +91,12 @@ __device__ __forceinline__ void count_cgt(const Block &k, uint32_t nb, uint32_t 
 // counts of A,C,G,T in rows [0, row] given the block that holds `row` (row already primary-adjusted)
 __device__ __forceinline__ void occ4_in_block(const Block &k, uint64_t row, uint64_t cnt[4])
 {
-	uint32_t nb = (uint32_t)(row & 127) + 1, c1, c2, c3;
+	uint32_t nb = ((uint32_t)row & OCC_MASK) + 1, c1, c2, c3;
 	count_cgt(k, nb, c1, c2, c3);
-	cnt[0] = u64_of(k.h0.x, k.h0.y) + (nb - c1 - c2 - c3);
-	cnt[1] = u64_of(k.h0.z, k.h0.w) + c1;
-	cnt[2] = u64_of(k.h1.x, k.h1.y) + c2;
-	cnt[3] = u64_of(k.h1.z, k.h1.w) + c3;
+	cnt[0] = (uint64_t)k.cnt.x + (nb - c1 - c2 - c3);
+	cnt[1] = (uint64_t)k.cnt.y + c1;
+	cnt[2] = (uint64_t)k.cnt.z + c2;
+	cnt[3] = (uint64_t)k.cnt.w + c3;
 }
 
 // bwt_occ4 (bwt.c:169-186)
@@ -97,7 +104,7 @@ __device__ __forceinline__ void occ4(const DevIndex &ix, uint64_t k, uint64_t cn
 {
 	bool none = (k == NONE64);
 	uint64_t row = none ? 0 : k - (k >= ix.primary);
-	Block b = load_block(ix, row >> 7);
+	Block b = load_block(ix, row >> OCC_SHIFT);
 	occ4_in_block(b, row, cnt);
 	if (none) cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
 }
@@ -110,13 +117,13 @@ __device__ __forceinline__ int occ2x4(const DevIndex &ix, uint64_t k, uint64_t l
 	bool kn = (k == NONE64), ln = (l == NONE64);
 	uint64_t rk = kn ? 0 : k - (k >= ix.primary);
 	uint64_t rl = ln ? 0 : l - (l >= ix.primary);
-	Block bk = load_block(ix, rk >> 7);
-	Block bl = load_block(ix, rl >> 7);
+	Block bk = load_block(ix, rk >> OCC_SHIFT);
+	Block bl = load_block(ix, rl >> OCC_SHIFT);
 	occ4_in_block(bk, rk, tk);
 	occ4_in_block(bl, rl, tl);
 	if (kn) tk[0] = tk[1] = tk[2] = tk[3] = 0;
 	if (ln) tl[0] = tl[1] = tl[2] = tl[3] = 0;
-	return (kn && ln) ? 0 : ((kn || ln) ? 1 : ((rk >> 7) != (rl >> 7) ? 2 : 1));
+	return (kn && ln) ? 0 : ((kn || ln) ? 1 : ((rk >> 7) != (rl >> 7) ? 2 : 1)); // 128-row blocks of the reference
 }
 
 __device__ __forceinline__ uint64_t sel4(int c, uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3)
@@ -164,26 +171,26 @@ __device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int 
 	uint64_t xa = IS_BACK ? ik.x0 : ik.x1, xb = IS_BACK ? ik.x1 : ik.x0;
 	uint64_t k = xa - 1, l = xa - 1 + ik.x2;
 	uint64_t rk = k - (k >= ix.primary), rl = l - (l >= ix.primary);
-	// Both rows usually fall into ONE block once the interval is small (bwt.c:194): then one line is requested, not two.
-	// The second load sits under the lane's predicate and is issued right behind the first, so when it is needed the two
-	// lines still travel together; nothing waits until the first use below.
-	const bool two = (rk >> 7) != (rl >> 7);
-	Block bk = load_block(ix, rk >> 7);
+	// Both rows usually fall into ONE record once the interval is small (bwt.c:194): then one record is requested, not
+	// two.  The second load sits under the lane's predicate and is issued right behind the first, so when it is needed the
+	// two still travel together; nothing waits until the first use below.
+	const bool two = (rk >> OCC_SHIFT) != (rl >> OCC_SHIFT);
+	Block bk = load_block(ix, rk >> OCC_SHIFT);
 	Block b2;
-	if (two) b2 = load_block(ix, rl >> 7);
-	// the select below must not be folded into the branch above (the compiler would then wait for the first block before
+	if (two) b2 = load_block(ix, rl >> OCC_SHIFT);
+	// the select below must not be folded into the branch above (the compiler would then wait for the first record before
 	// issuing the second in order to copy it): hide the predicate behind an empty asm
 	uint32_t two_sel = two ? 1u : 0u;
 	asm volatile("" : "+v"(two_sel));
 	Block bl;
-	bl.h0 = two_sel ? b2.h0 : bk.h0; bl.h1 = two_sel ? b2.h1 : bk.h1; bl.lo = two_sel ? b2.lo : bk.lo; bl.hi = two_sel ? b2.hi : bk.hi;
-	uint32_t nk = (uint32_t)(rk & 127) + 1, nl = (uint32_t)(rl & 127) + 1, k1, k2, k3, l1, l2, l3;
+	bl.cnt = two_sel ? b2.cnt : bk.cnt; bl.pl = two_sel ? b2.pl : bk.pl;
+	uint32_t nk = ((uint32_t)rk & OCC_MASK) + 1, nl = ((uint32_t)rl & OCC_MASK) + 1, k1, k2, k3, l1, l2, l3;
 	count_cgt(bk, nk, k1, k2, k3);
 	count_cgt(bl, nl, l1, l2, l3);
-	uint64_t tk0 = u64_of(bk.h0.x, bk.h0.y) + (nk - k1 - k2 - k3), tl0 = u64_of(bl.h0.x, bl.h0.y) + (nl - l1 - l2 - l3);
-	uint64_t tk1 = u64_of(bk.h0.z, bk.h0.w) + k1, tl1 = u64_of(bl.h0.z, bl.h0.w) + l1;
-	uint64_t tk2 = u64_of(bk.h1.x, bk.h1.y) + k2, tl2 = u64_of(bl.h1.x, bl.h1.y) + l2;
-	uint64_t tk3 = u64_of(bk.h1.z, bk.h1.w) + k3, tl3 = u64_of(bl.h1.z, bl.h1.w) + l3;
+	uint64_t tk0 = (uint64_t)bk.cnt.x + (nk - k1 - k2 - k3), tl0 = (uint64_t)bl.cnt.x + (nl - l1 - l2 - l3);
+	uint64_t tk1 = (uint64_t)bk.cnt.y + k1, tl1 = (uint64_t)bl.cnt.y + l1;
+	uint64_t tk2 = (uint64_t)bk.cnt.z + k2, tl2 = (uint64_t)bl.cnt.z + l2;
+	uint64_t tk3 = (uint64_t)bk.cnt.w + k3, tl3 = (uint64_t)bl.cnt.w + l3;
 	uint64_t s0 = tl0 - tk0, s1 = tl1 - tk1, s2 = tl2 - tk2, s3 = tl3 - tk3;
 	uint64_t tkc = sel4(c, tk0, tk1, tk2, tk3);
 	uint64_t sc  = sel4(c, s0, s1, s2, s3);
@@ -213,10 +220,10 @@ __device__ __forceinline__ uint64_t inv_psi(const DevIndex &ix, uint64_t k)
 {
 	if (k == ix.primary) return 0;
 	uint64_t row = k - (k > ix.primary);
-	Block b = load_block(ix, row >> 7);
-	uint32_t p = (uint32_t)(row & 127), w = p >> 5, bit = p & 31;
-	uint32_t lo = w == 0 ? b.lo.x : w == 1 ? b.lo.y : w == 2 ? b.lo.z : b.lo.w;
-	uint32_t hi = w == 0 ? b.hi.x : w == 1 ? b.hi.y : w == 2 ? b.hi.z : b.hi.w;
+	Block b = load_block(ix, row >> OCC_SHIFT);
+	uint32_t p = (uint32_t)row & OCC_MASK, w = p >> 5, bit = p & 31;
+	uint32_t lo = w == 0 ? b.pl.x : b.pl.y;
+	uint32_t hi = w == 0 ? b.pl.z : b.pl.w;
 	int c = (int)(((lo >> bit) & 1u) | (((hi >> bit) & 1u) << 1));
 	uint64_t cnt[4];
 	occ4_in_block(b, row, cnt);
