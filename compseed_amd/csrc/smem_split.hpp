@@ -60,6 +60,7 @@ struct SplitArgs {
 	unsigned long long *err;                          // sticky: a queue overflowed
 	unsigned long long *n_sst_hits;                   // bwt_extend queries answered by the on-device SST
 	int32_t   sst;                                    // cs_params_t.sst_mode
+	uint4    *sst2;                                   // second SST level (global, SST2_ENTRIES)
 };
 
 __device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const Intv &v, uint32_t beg, uint32_t end)
@@ -104,6 +105,14 @@ __device__ __forceinline__ uint64_t emit_smem(const SplitArgs &A, uint32_t r, ui
 // block answers it, so only an LDS-resident level set saves anything.
 constexpr int SST_K = 5;
 constexpr int SST_ENTRIES = 4 + 16 + 64 + 256 + 1024;
+// Optional second level: strings of SST_K+1 .. SST2_K bases in a table in global memory (L2-resident, persistent across
+// launches).  MEASURED AND SWITCHED OFF (SST2_K == SST_K): with SST2_K = 8 (1.4 MB) the hit rate rose from 8.8 % to
+// 18.8 % on the bench workload but the SMEM stage got 10 % SLOWER (224 vs 204 ms per 10 M reads) -- the Occ records of
+// such short strings are L2 hits already, so a hit only trades two record reads for one table read plus divergence.
+// Only a level that answers without leaving the CU (LDS) pays.  The code path is kept for the record.
+constexpr int SST2_K = SST_K;
+constexpr int SST2_ENTRIES = 4096 + 16384 + 65536;
+__device__ __forceinline__ int sst2_index(int len, uint32_t code) { return ((1 << (2 * len)) - 4096) / 3 + (int)code; } // len in 6..8
 __device__ __forceinline__ int sst_index(int len, uint32_t code) // len in 1..SST_K
 {
 	return ((1 << (2 * len)) - 4) / 3 + (int)code; // 4 + 16 + ... + 4^(len-1) entries precede length `len`
@@ -113,14 +122,17 @@ __device__ __forceinline__ void sst_clear(uint4 *sst)
 	for (int t = threadIdx.x; t < SST_ENTRIES; t += blockDim.x) sst[t] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
 	__syncthreads();
 }
-__device__ __forceinline__ bool sst_get(const uint4 *sst, int len, uint32_t code, Intv &v)
+__device__ __forceinline__ bool sst_get(const uint4 *sst, uint4 *sst2, int len, uint32_t code, Intv &v)
 {
-	uint4 e = sst[sst_index(len, code)];
+	uint4 e = len <= SST_K ? sst[sst_index(len, code)] : sst2[sst2_index(len, code)];
 	if (e.w == 0xffffffffu) return false; // empty: a stored entry keeps its top 16 bits (the unused query end) zero
 	uint32_t end; unpack_lep(e, v, end);
 	return true;
 }
-__device__ __forceinline__ void sst_put(uint4 *sst, int len, uint32_t code, const Intv &v) { sst[sst_index(len, code)] = pack_lep(v, 0); }
+__device__ __forceinline__ void sst_put(uint4 *sst, uint4 *sst2, int len, uint32_t code, const Intv &v)
+{
+	if (len <= SST_K) sst[sst_index(len, code)] = pack_lep(v, 0); else sst2[sst2_index(len, code)] = pack_lep(v, 0);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // initial tasks: round-1 call at the first unambiguous base, and the round-3 chain (bwamem.c:226, 253)
@@ -258,14 +270,14 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 		// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
 		uint32_t b = i < len ? rd.at(i) : 4u;
 		Intv y = ik;
-		bool cached = false, cacheable = use_sst && b <= 3 && slen < SST_K;
+		bool cached = false, cacheable = use_sst && b <= 3 && slen < SST2_K;
 		uint32_t ccode = scode << 2 | b;                    // the string extended by read base b
-		if (cacheable) cached = sst_get(sst, slen + 1, ccode, y);
+		if (cacheable) cached = sst_get(sst, A.sst2, slen + 1, ccode, y);
 		if (b <= 3) {
 			++my_q;
 			if (cached) ++my_hits;
-			else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, slen + 1, ccode, y); }
-			scode = ccode; ++slen;                          // slen keeps counting; only values < SST_K are looked at
+			else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
+			scode = ccode; ++slen;                          // slen keeps counting; only values < SST2_K are looked at
 		}
 
 		if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
@@ -308,7 +320,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
                                                unsigned long long &my_q, unsigned long long &my_hits, uint4 *sst)
 {
 	const bool use_sst = A.sst != 0;
-	int slen = SST_K; uint32_t scode = 0; // this lane's match as a string, while it is short enough for the SST
+	int slen = SST2_K; uint32_t scode = 0; // this lane's match as a string, while it is short enough for the SST
 	constexpr uint32_t MYCLS = G == 16 ? 0u : G == 32 ? 1u : 2u;
 	const DevIndex &ix = A.ix;
 	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, gbase = lane - gl; // group = G consecutive lanes of a wave
@@ -361,8 +373,8 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				uint64_t rb = A.off[r];
 				rd.start(A.seq, rb, x - 1);
 				i = x - 1; nm = 0; last_start = 0;
-				slen = SST_K; scode = 0;
-				if (use_sst && live && (int)pend - x < SST_K) { // a short LEP: spell it, the SST is keyed by the string
+				slen = SST2_K; scode = 0;
+				if (use_sst && live && (int)pend - x < SST2_K) { // a short LEP: spell it, the SST is keyed by the string
 					slen = (int)pend - x;
 					for (int q = 0; q < slen; ++q) scode = scode << 2 | A.seq[rb + x + q];
 				}
@@ -381,14 +393,14 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				end_call = true;
 			} else {
 				Intv y = e;
-				bool cacheable = use_sst && live && slen < SST_K, cached = false;
+				bool cacheable = use_sst && live && slen < SST2_K, cached = false;
 				uint32_t ccode = b << (2 * slen) | scode;       // read base b in front of the string
-				if (cacheable) cached = sst_get(sst, slen + 1, ccode, y);
+				if (cacheable) cached = sst_get(sst, A.sst2, slen + 1, ccode, y);
 				if (live) {
 					++my_q;
 					if (cached) ++my_hits;
-					else { y = extend1<true>(ix, e, (int)b); if (cacheable) sst_put(sst, slen + 1, ccode, y); }
-					if (slen < SST_K) { scode = ccode; ++slen; }
+					else { y = extend1<true>(ix, e, (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
+					if (slen < SST2_K) { scode = ccode; ++slen; }
 				}
 				bool stop = live && y.x2 < min_intv, cand = live && !stop;
 				uint64_t cand_m = __ballot(cand) & gmask;
@@ -558,13 +570,28 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 	if (r >= n_reads) return;
 	uint32_t n = cnt[r];
 	const OutMem *src = raw + (size_t)r * cap;
+	OutMem *dst = mems + mem_off[r];
+	if (n <= 16 && n <= cap) { // the common case: keys in registers, ranks by 16 x 16 compares, no re-reads
+		uint64_t k[16];
+#pragma unroll
+		for (int a = 0; a < 16; ++a) k[a] = (uint32_t)a < n ? src[a].info : ~0ull;
+#pragma unroll
+		for (int a = 0; a < 16; ++a) {
+			if ((uint32_t)a < n) {
+				uint32_t rank = 0;
+#pragma unroll
+				for (int b = 0; b < 16; ++b) rank += (k[b] < k[a]) || (k[b] == k[a] && b < a); // padding keys are never smaller
+				dst[rank] = src[a];
+			}
+		}
+		return;
+	}
 	uint64_t olo = 0;
 	if (n > cap) { // lower bound of r among the sorted overflow keys
 		uint64_t lo = 0, hi = n_ovf;
 		while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ovf_key[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
 		olo = lo;
 	}
-	OutMem *dst = mems + mem_off[r];
 	for (uint32_t a = 0; a < n; ++a) {
 		OutMem ma = mem_at(src, cap, ovf, ovf_idx, olo, a);
 		uint32_t rank = 0;
