@@ -84,8 +84,8 @@ template <typename T> struct PinBuf {
 struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
-	hipStream_t stream = nullptr, stream2 = nullptr; // stream2: the independent round-3 chains, filling the other launches' tails
-	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; // stream2: the independent round-3 chains; stream3: wide sweeps
+	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
@@ -200,6 +200,9 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		HIP_TRY(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_r3a, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_r3b, hipEventDisableTiming));
+		HIP_TRY(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_wa, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_wb, hipEventDisableTiming));
 	}
 
 	if (v->seq_len == 0 || v->seq_len != v->L2[4] || v->L2[0] != 0) return fail(CS_EINVAL, "index view: L2 / seq_len inconsistent");
@@ -308,6 +311,9 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
 	if (e->ev_r3a) (void)hipEventDestroy(e->ev_r3a);
 	if (e->ev_r3b) (void)hipEventDestroy(e->ev_r3b);
+	if (e->ev_wa) (void)hipEventDestroy(e->ev_wa);
+	if (e->ev_wb) (void)hipEventDestroy(e->ev_wb);
+	if (e->stream3) (void)hipStreamDestroy(e->stream3);
 	if (e->stream2) (void)hipStreamDestroy(e->stream2);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
@@ -490,15 +496,21 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			if (!r3_only) { // one launch works through all four size classes of the chunk's backward sweeps
 				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
+				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed
+				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
+				hipLaunchKernelGGL(bwd_wide_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				                   (const BTask *)e->d_bq.p, cn, C + 5);
+				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
 				hipLaunchKernelGGL((bwd_all_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A,
 				                   (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // both must be done before the slots and the LEP arena are reused
 			}
 			c0 += cn;
 		}
 		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
-		if (H[7]) { (void)hipStreamSynchronize(e->stream2); return 1; }
+		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); return 1; }
 		n_f = H[1];
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
 		std::swap(cur, nxt);

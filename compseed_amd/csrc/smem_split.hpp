@@ -496,27 +496,44 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 	}
 }
 
-// All backward work of one forward launch in ONE kernel: every wave works through the four size classes, starting with
-// a different one depending on its workgroup, so all classes progress at once and a wave whose class runs dry moves on
-// to the next instead of idling through that class's tail.  ctrs[c] is the slot counter of class c.
+// All cooperative backward work of one forward launch in ONE kernel: every wave works through the three size classes,
+// starting with a different one depending on its workgroup, so all classes progress at once and a wave whose class runs
+// dry moves on to the next instead of idling through that class's tail.  The three orders are written out (a loop over a
+// class index costs 35 more VGPRs and one wave per SIMD).  ctrs[c] is the slot counter of class c.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 4) void bwd_all_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
+__global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
 	WaveOut O = {0, 0};
 	unsigned long long my_q = 0, my_hits = 0;
 	__shared__ uint4 sst[SST_ENTRIES];
 	sst_clear(sst);
-	const uint32_t role = blockIdx.x & 7u, first = role < 5 ? 0u : role - 4u; // 5/8 of the workgroups start on the <=16 class
-	for (uint32_t k = 0; k < 4; ++k) {
-		uint32_t c = (first + k) & 3u;
-		if (c == 0) bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
-		else if (c == 1) bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
-		else if (c == 2) bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
-		else bwd_wide_run(A, bq, n_tasks, ctrs + 3, O, my_q);
+	const uint32_t role = blockIdx.x & 7u; // 5/8 of the workgroups start on the <=16 class, 2/8 on <=32, 1/8 on <=64
+	if (role < 5) {
+		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
+		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
+		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
+	} else if (role < 7) {
+		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
+		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
+		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
+	} else {
+		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
+		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
+		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
 	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+}
+
+// the calls with more than 64 LEPs, one wave each; rare, so it runs beside bwd_all_kernel on its own stream
+__global__ __launch_bounds__(256) void bwd_wide_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr)
+{
+	WaveOut O = {0, 0};
+	unsigned long long my_q = 0;
+	bwd_wide_run(A, bq, n_tasks, ctr, O, my_q);
+	wave_push_finish(O, A);
+	atomicAdd(A.n_queries, my_q);
 }
 
 // one lane, list in HBM, compacted in place (reference form of the sweep; kept for A/B tests of the wide path)
