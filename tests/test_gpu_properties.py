@@ -1,0 +1,162 @@
+"""Size-independent properties of the hot path at sizes the golden vectors cannot cover (GPU, through the C ABI).
+
+A 64 Mbp synthetic genome is indexed on the GPU and 400,000 x 150 bp reads are seeded; the checks need no oracle
+run over the full set: sortedness and filters, every seed position verified against the text, strand symmetry of the
+bi-intervals, invariance under batch splitting / SST mode / kernel variant, and a bit-exact oracle comparison on a sample.
+The last test repeats the cheap properties at BASELINE.json's full size (hg19-scale index, 10 M x 150 bp reads).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def world():
+    import torch
+    import compseed_amd as ca
+    import synth
+    G = synth.make_genome(64_000_000, seed=11, device="cuda")
+    g = G.cpu().numpy()
+    ix = ca.Index.build(g, 0)
+    eng = ca.Engine(ix, 0)
+    bases, off = synth.make_reads(G, 400_000, 150, seed=5, p_sub=0.01, p_n=0.0005, sort=True)
+    hb, ho = bases.cpu().numpy(), off.cpu().numpy().astype(np.uint64)
+    del G
+    torch.cuda.empty_cache()
+    res = eng.seed_batch(hb, ho)
+    yield dict(ca=ca, g=g, ix=ix, eng=eng, bases=hb, off=ho, res=res)
+    eng.close(); ix.close()
+
+
+def _text(g):
+    return np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])  # forward ++ reverse complement (bntseq.c:306-312)
+
+
+def _codes(ascii_bases):
+    lut = np.full(256, 4, np.uint8)
+    for ch, v in zip(b"ACGT", range(4)):
+        lut[ch] = v
+    return lut[ascii_bases]
+
+
+def test_sorted_filtered_and_consistent(world):
+    r = world["res"]
+    m = r.mems
+    beg = (m["info"] >> np.uint64(32)).astype(np.int64); end = (m["info"] & np.uint64(0xffffffff)).astype(np.int64)
+    assert (end - beg >= 19).all() and (m["x2"] >= 1).all()                       # length filter, non-empty intervals
+    assert (end <= 150).all() and (beg >= 0).all()
+    rd = np.repeat(np.arange(r.n_reads), np.diff(r.mem_off.astype(np.int64)))
+    same = rd[1:] == rd[:-1]
+    assert (m["info"][1:][same] >= m["info"][:-1][same]).all()                    # sorted by info inside a read (comp_seed.cpp:2301)
+    n = world["ix"].view.seq_len
+    assert (m["x0"] + m["x2"] <= n + 1).all() and (m["x1"] + m["x2"] <= n + 1).all()
+    # SAL: min(x2, max_occ) slots per mem, in mem order (comp_seed.cpp:2313-2325)
+    per_mem = np.minimum(m["x2"], 500).astype(np.int64)
+    assert per_mem.sum() == r.n_seeds
+    so = np.concatenate([[0], np.cumsum(per_mem)])
+    assert np.array_equal(r.seed_off.astype(np.int64), so[r.mem_off.astype(np.int64)])
+    assert np.array_equal(r.seeds["qbeg"], np.repeat(beg, per_mem)) and np.array_equal(r.seeds["len"], np.repeat(end - beg, per_mem))
+
+
+def test_every_seed_matches_the_text(world):
+    """end-to-end: read[qbeg:qbeg+len] == T[rbeg:rbeg+len] for every one of the ~4 M seeds (checks x0 and the SA path)"""
+    r = world["res"]; T = _text(world["g"]); q = _codes(world["bases"])
+    rd = np.repeat(np.arange(r.n_reads), np.diff(r.seed_off.astype(np.int64)))
+    qpos = world["off"][rd].astype(np.int64) + r.seeds["qbeg"]
+    rbeg = r.seeds["rbeg"].astype(np.int64); ln = r.seeds["len"].astype(np.int64)
+    assert (rbeg >= 0).all() and (rbeg + ln <= T.size).all()
+    ok = np.ones(rbeg.size, bool)
+    for d in range(int(ln.max())):
+        act = ln > d
+        ok[act] &= T[rbeg[act] + d] == q[qpos[act] + d]
+    assert ok.all()
+
+
+def test_strand_symmetry(world):
+    """the SMEM set of a read (round 1 only: -y 0 disables round 3, a huge -r disables re-seeding, both of which walk the
+    read left to right and are not symmetric) is mirrored by reverse-complementing the read: x0 <-> x1, [beg,end) -> [L-end, L-beg)"""
+    ca, eng = world["ca"], world["eng"]
+    n = 20000
+    q = world["bases"][: n * 150].reshape(n, 150)
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGTN")] = list(b"TGCAN")
+    rc = comp[q[:, ::-1]].reshape(-1)
+    off = world["off"][: n + 1]
+    a = eng.seed_batch(q.reshape(-1), off, ca.Params(want_sal=0, y=0, r=100.0))
+    b = eng.seed_batch(rc, off, ca.Params(want_sal=0, y=0, r=100.0))
+    assert np.array_equal(a.mem_off, b.mem_off)
+    ka = np.stack([np.repeat(np.arange(n), np.diff(a.mem_off.astype(np.int64))), 150 - (a.mems["info"] & np.uint64(0xffffffff)).astype(np.int64),
+                   150 - (a.mems["info"] >> np.uint64(32)).astype(np.int64), a.mems["x1"].astype(np.int64), a.mems["x0"].astype(np.int64), a.mems["x2"].astype(np.int64)], 1)
+    kb = np.stack([np.repeat(np.arange(n), np.diff(b.mem_off.astype(np.int64))), (b.mems["info"] >> np.uint64(32)).astype(np.int64),
+                   (b.mems["info"] & np.uint64(0xffffffff)).astype(np.int64), b.mems["x0"].astype(np.int64), b.mems["x1"].astype(np.int64), b.mems["x2"].astype(np.int64)], 1)
+    ka = ka[np.lexsort(ka.T[::-1])]; kb = kb[np.lexsort(kb.T[::-1])]
+    assert np.array_equal(ka, kb)
+
+
+def test_invariance_under_batching_sst_and_kernel_variant(world, monkeypatch):
+    ca, eng, res = world["ca"], world["eng"], world["res"]
+    hb, ho = world["bases"], world["off"]
+    again = eng.seed_batch(hb, ho)                                          # determinism despite atomics / task order
+    assert np.array_equal(again.mems, res.mems) and np.array_equal(again.seeds, res.seeds)
+    off_sst = eng.seed_batch(hb, ho, ca.Params(sst_mode=0))
+    assert np.array_equal(off_sst.mems, res.mems) and np.array_equal(off_sst.mem_off, res.mem_off)
+    cut = 123_457                                                           # results of a read do not depend on its batch
+    p1 = eng.seed_batch(hb[: cut * 150], ho[: cut + 1])
+    p2 = eng.seed_batch(hb[cut * 150:], ho[cut:] - ho[cut])
+    assert np.array_equal(np.concatenate([p1.mems, p2.mems]), res.mems) and np.array_equal(np.concatenate([p1.seeds, p2.seeds]), res.seeds)
+    monkeypatch.setenv("CS_SMEM_MODE", "fused")                             # second, independent implementation
+    e2 = ca.Engine(world["ix"], 0)
+    f = e2.seed_batch(hb[: 60000 * 150], ho[: 60001])
+    e2.close()
+    k = int(res.mem_off[60000])
+    assert np.array_equal(f.mems, res.mems[:k]) and np.array_equal(f.seeds, res.seeds[: int(res.seed_off[60000])])
+
+
+def test_sample_is_bit_exact_vs_oracle(world):
+    bw, sa = world["ix"].arrays()
+    v = world["ix"].view
+    o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
+    n = 30000
+    want = o.seed_batch(world["bases"][: n * 150], world["off"][: n + 1], mode=1, threads=8)
+    r = world["res"]
+    assert np.array_equal(r.mem_off[: n + 1], want["mem_off"]) and np.array_equal(r.mems[: int(r.mem_off[n])], want["mems"])
+    assert np.array_equal(r.seeds[: int(r.seed_off[n])], want["seeds"])
+
+
+def test_full_baseline_size_properties():
+    """BASELINE configs[1] shape: hg19-size index, 10 M x 150 bp reads, defaults; cheap size-independent checks on device
+    results without copying 5 GB back: counts, sortedness, filters, and a checksum that must not change between two runs."""
+    import torch
+    import compseed_amd as ca
+    import synth
+    G = synth.make_genome(3_100_000_000, seed=20261003, device="cuda")
+    ix = ca.Index.build(G.cpu().numpy(), 0)
+    bases, off = synth.make_reads(G, 10_000_000, 150, seed=777, p_sub=0.005, sort=True)
+    del G
+    torch.cuda.empty_cache()
+    eng = ca.Engine(ix, 0)
+    sums = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        r = eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), 10_000_000, bases.numel())
+        mo = eng.download(r.ptr["mem_off"], np.uint64, 10_000_001)
+        assert int(mo[-1]) == r.n_mems and (np.diff(mo.astype(np.int64)) >= 0).all()
+        chk = 0
+        step = 4_000_000
+        for s in range(0, r.n_mems, step):                                   # stream the mems through the host in pieces
+            k = min(step, r.n_mems - s)
+            m = eng.download(r.ptr["mems"] + s * 32, ca.INTV_DT, k)
+            beg = (m["info"] >> np.uint64(32)).astype(np.int64); end = (m["info"] & np.uint64(0xffffffff)).astype(np.int64)
+            assert (end - beg >= 19).all() and (end <= 150).all() and (m["x2"] >= 1).all()
+            chk ^= int(np.bitwise_xor.reduce(m["x0"] * np.uint64(0x9E3779B97F4A7C15) + m["x1"] + (m["info"] << np.uint64(1)) + m["x2"]))
+        rd_first = mo[:-1][np.diff(mo.astype(np.int64)) > 0]
+        sums.append((r.n_mems, r.n_seeds, chk, int(rd_first.size)))
+    assert sums[0] == sums[1] and sums[0][0] > 50_000_000
+    eng.close(); ix.close()
