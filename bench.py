@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("CS_BENCH_READS", "10000000")), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-sal", action="store_true")
+    ap.add_argument("--host-io", action="store_true", help="also time the host-buffer variant (PCIe in and out) after the timed region")
     ap.add_argument("--sst", type=int, default=int(os.environ.get("CS_BENCH_SST", "1")), help="on-device SST memo (1 = on, 0 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-for-bit against the oracle after the timed region")
@@ -176,6 +177,14 @@ def main():
             out["cpu_baseline"] = {"value": ncpu / dt, "unit": "reads/s", "cores": cores, "kind": "port",
                                    "sample": "first %d reads of rank 0's batch, oracle/cs_oracle.c in CompSeed mode (SST per 512 reads), %d threads, %.1f s"
                                              % (ncpu, cores, dt)}
+        if args.host_io:  # the boundary's host-buffer form: reads from pageable host memory, results into pinned host memory
+            hb_all = bases.cpu().numpy(); ho_all = off.cpu().numpy().astype(np.uint64)
+            eng.seed_batch(hb_all, ho_all, par, copy=False)  # warm-up: pinned result buffers are allocated on first use
+            tp = time.perf_counter()
+            eng.seed_batch(hb_all, ho_all, par, copy=False)
+            dt = time.perf_counter() - tp
+            out["pcie_inclusive"] = {"reads_per_s": args.reads / dt, "ms_per_step": 1e3 * dt,
+                                     "note": "cs_engine_seed_batch: H2D of the reads + D2H of mems and seeds, not overlapped; never `value`"}
         print(json.dumps(out), flush=True)
     D.close()
     eng.close(); ix.close()

@@ -192,23 +192,24 @@ class Index:
 class Result:
     """CSR result of one batch as numpy arrays (host variant) or raw device pointers (device variant)."""
 
-    def __init__(self, cres, on_device, want_sal):
+    def __init__(self, cres, on_device, want_sal, copy=True):
         self.n_reads, self.n_mems, self.n_seeds = int(cres.n_reads), int(cres.n_mems), int(cres.n_seeds)
         self.on_device = on_device
         self.ptr = dict(mem_off=cres.mem_off, mems=cres.mems, seed_off=cres.seed_off, seeds=cres.seeds)
         if not on_device:
-            self.mem_off = _view(cres.mem_off, "<u8", self.n_reads + 1)
-            self.mems = _view(cres.mems, INTV_DT, self.n_mems)
-            self.seed_off = _view(cres.seed_off, "<u8", self.n_reads + 1) if want_sal else None
-            self.seeds = _view(cres.seeds, SEED_DT, self.n_seeds) if want_sal else None
+            self.mem_off = _view(cres.mem_off, "<u8", self.n_reads + 1, copy)
+            self.mems = _view(cres.mems, INTV_DT, self.n_mems, copy)
+            self.seed_off = _view(cres.seed_off, "<u8", self.n_reads + 1, copy) if want_sal else None
+            self.seeds = _view(cres.seeds, SEED_DT, self.n_seeds, copy) if want_sal else None
 
 
-def _view(ptr, dt, n):
+def _view(ptr, dt, n, copy=True):
     dt = np.dtype(dt)
     if n == 0 or not ptr:
         return np.zeros(0, dtype=dt)
     buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
-    return np.frombuffer(buf, dtype=dt, count=n).copy()
+    a = np.frombuffer(buf, dtype=dt, count=n)
+    return a.copy() if copy else a  # copy=False: a view of the engine's pinned buffer, valid until the next call
 
 
 class Engine:
@@ -233,14 +234,15 @@ class Engine:
             pass
 
     # ---- hot path
-    def seed_batch(self, bases, offsets, params=None):
-        """Host buffers in, numpy CSR out (cs_engine_seed_batch)."""
+    def seed_batch(self, bases, offsets, params=None, copy=True):
+        """Host buffers in, numpy CSR out (cs_engine_seed_batch).  copy=False returns views of the engine's pinned
+        result buffers (valid until the next call on this engine) instead of copies."""
         params = params or Params()
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         res = CResult()
         _check(self._L.cs_engine_seed_batch(self._h, C.byref(params), offsets.size - 1, bases.ctypes.data, offsets.ctypes.data, C.byref(res)))
-        return Result(res, False, bool(params.want_sal))
+        return Result(res, False, bool(params.want_sal), copy)
 
     def seed_batch_device(self, d_bases, d_offsets, n_reads, n_bases, params=None):
         """Device pointers (ints) in, device pointers out (cs_engine_seed_batch_device): no PCIe traffic in the call."""
