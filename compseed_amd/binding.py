@@ -54,7 +54,8 @@ class Stats(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libcompseed_amd.so")
+    # CS_LIB: load an alternative build of the same library (A/B experiments); the default is the in-tree build
+    return os.environ.get("CS_LIB") or os.path.join(_HERE, "libcompseed_amd.so")
 
 
 def build_library(force=False):

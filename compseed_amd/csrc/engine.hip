@@ -102,7 +102,7 @@ struct cs_engine {
 	PinBuf<uint64_t> h_mem_off, h_seed_off; PinBuf<OutMem> h_mems; PinBuf<OutSeed> h_seeds;
 	PinBuf<unsigned long long> h_ctr;
 	// split (forward / cooperative backward) SMEM path
-	DevBuf<uint64_t> d_fqA, d_fqB, d_fqR; DevBuf<uint4> d_sst2; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
+	DevBuf<uint64_t> d_fqA, d_fqB, d_fqR; DevBuf<uint4> d_sst2, d_jump; int jump_k = 0; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
 	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
 	int smem_mode = 1;          // 1 = split kernels (default), 0 = fused one-lane-per-read kernel (CS_SMEM_MODE=fused)
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
@@ -277,6 +277,19 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		}
 	}
 
+	// round-3 jump table (smem_split.hpp): every 15-mer, 17 GB (13: 1 GB, measured 2 % slower); CS_JUMP_K = 0 disables
+	{
+		int jk = 15;
+		if (const char *s = getenv("CS_JUMP_K")) jk = atoi(s);
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		if (jk >= 6 && jk <= 15 && ((size_t)16 << (2 * jk)) + ((size_t)8 << 30) < free_b) {
+			CS_TRY(e->d_jump.reserve((size_t)1 << (2 * jk)));
+			hipLaunchKernelGGL(jump_fill_kernel, dim3((unsigned)(e->n_cu * 32)), dim3(256), 0, e->stream, ix, jk, e->d_jump.p);
+			HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
+			e->jump_k = jk;
+		}
+	}
 	if (verbose) { fprintf(stderr, "[cs_engine] full suffix array: %s\n", ix.fsa32 ? "4-byte" : ix.fsa64 ? "8-byte" : "off"); fflush(stderr); }
 	if (const char *s = getenv("CS_LEP_LDS")) { int v = atoi(s); g_lep_lds = (v == 10 || v == 13) ? v : 20; }
 	if (const char *s = getenv("CS_MEM_CAP")) { int c = atoi(s); if (c >= 1 && c <= 4096) e->cap = (uint32_t)c; }
@@ -305,7 +318,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
-	e->d_fqA.release(); e->d_fqB.release(); e->d_fqR.release(); e->d_sst2.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
+	e->d_fqA.release(); e->d_fqB.release(); e->d_fqR.release(); e->d_sst2.release(); e->d_jump.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
 	e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -462,7 +475,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.split_width = (uint32_t)par->split_width; A.max_mem_intv = par->max_mem_intv;
 	A.bq = e->d_bq.p;
 	A.lep = e->d_lep.p; A.lep_stride = stride;
-	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p;
+	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p; A.jump = e->jump_k ? e->d_jump.p : nullptr; A.jump_k = e->jump_k;
 	A.fq_cap = fq_cap; A.n_f_next = C + 1;
 
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;

@@ -61,6 +61,7 @@ struct SplitArgs {
 	unsigned long long *n_sst_hits;                   // bwt_extend queries answered by the on-device SST
 	int32_t   sst;                                    // cs_params_t.sst_mode
 	uint4    *sst2;                                   // second SST level (global, SST2_ENTRIES)
+	const uint4 *jump; int32_t jump_k;                // round-3 jump table: bi-interval of every jump_k-mer (or null)
 };
 
 __device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const Intv &v, uint32_t beg, uint32_t end)
@@ -110,8 +111,11 @@ constexpr int SST_ENTRIES = 4 + 16 + 64 + 256 + 1024;
 // 18.8 % on the bench workload but the SMEM stage got 10 % SLOWER (224 vs 204 ms per 10 M reads) -- the Occ records of
 // such short strings are L2 hits already, so a hit only trades two record reads for one table read plus divergence.
 // Only a level that answers without leaving the CU (LDS) pays.  The code path is kept for the record.
-constexpr int SST2_K = SST_K;
-constexpr int SST2_ENTRIES = 4096 + 16384 + 65536;
+#ifndef CS_SST2_K
+#define CS_SST2_K 5
+#endif
+constexpr int SST2_K = CS_SST2_K;
+constexpr int SST2_ENTRIES = SST2_K > SST_K ? ((1 << (2 * (SST2_K + 1))) - 4096) / 3 : 16;
 __device__ __forceinline__ int sst2_index(int len, uint32_t code) { return ((1 << (2 * len)) - 4096) / 3 + (int)code; } // len in 6..8
 __device__ __forceinline__ int sst_index(int len, uint32_t code) // len in 1..SST_K
 {
@@ -132,6 +136,24 @@ __device__ __forceinline__ bool sst_get(const uint4 *sst, uint4 *sst2, int len, 
 __device__ __forceinline__ void sst_put(uint4 *sst, uint4 *sst2, int len, uint32_t code, const Intv &v)
 {
 	if (len <= SST_K) sst[sst_index(len, code)] = pack_lep(v, 0); else sst2[sst2_index(len, code)] = pack_lep(v, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round-3 jump table.  bwt_seed_strategy1 (bwt.c:358-379) extends forward from a start x and looks at the interval only
+// once i - x >= min_seed_len, so the first min_seed_len bases of every segment are pure pointer chasing whose
+// intermediate intervals nobody reads -- and at those depths the interval is still wide, so every step costs TWO random
+// records.  The bi-interval of every k-mer (k = jump_k <= min_seed_len) is therefore precomputed once per engine into a
+// table in HBM (4^15 x 16 B = 17 GB by default: this is what 288 GB are for) and a segment starts with ONE lookup instead of k - 1
+// extensions.  A k-mer that does not occur has size 0 and every later extension keeps it at 0, exactly as in the
+// reference, so the emitted seeds are unchanged; the skipped steps are counted as queries answered by the cache.
+__global__ void jump_fill_kernel(const DevIndex ix, int k, uint4 *table)
+{
+	uint64_t n = 1ull << (2 * k);
+	for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (uint64_t)gridDim.x * blockDim.x) {
+		Intv v = set_intv(ix, (int)((m >> (2 * (k - 1))) & 3));
+		for (int j = k - 2; j >= 0; --j) v = extend1<false>(ix, v, 3 - (int)((m >> (2 * j)) & 3));
+		table[m] = pack_lep(v, 0);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -246,6 +268,23 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 	sst_clear(sst);
 	const bool use_sst = A.sst != 0;
 	int slen = 0; uint32_t scode = 0; // the string matched so far, while it is short enough for the SST
+	const int jump_k = (use_sst && A.jump && A.jump_k <= A.min_seed_len) ? A.jump_k : 0;
+	// start a round-3 segment at x: through the jump table when the next jump_k bases are all A/C/G/T, else base by base
+	auto r3_start = [&]() {
+		if (jump_k && x + jump_k <= len) {
+			uint32_t code = 0; bool clean = true;
+			for (int q = 0; q < jump_k; ++q) { uint32_t bq = rd.at(x + q); clean = clean && bq <= 3; code = code << 2 | (bq & 3); }
+			if (clean) {
+				uint32_t e; unpack_lep(A.jump[code], ik, e);
+				i = x + jump_k; slen = jump_k; scode = 0;
+				my_q += (unsigned)(jump_k - 1); my_hits += (unsigned)(jump_k - 1);
+				return;
+			}
+			rd.start(A.seq, A.off[r], x); // the reader only moves forward: rewind it to the segment start
+		}
+		scode = rd.at(x); slen = 1;
+		ik = set_intv(ix, (int)scode); i = x + 1;
+	};
 
 	for (;;) {
 		uint64_t t_id = 0;
@@ -261,7 +300,10 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 					rd.start(A.seq, rb, x);
 					lep = A.lep + tslot * A.lep_stride; n = 0;
 					if (kind == TK_ROUND3) while (x < len && rd.at(x) > 3) ++x; // first start (bwamem.c:255-256)
-					if (x < len) { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; active = true; }
+					if (x < len) {
+						if (kind == TK_ROUND3) r3_start(); else { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; }
+						active = true;
+					}
 				}
 			}
 		}
@@ -287,8 +329,7 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 			x = i + 1; // restart behind the seed / the ambiguous base
 			while (x < len && rd.at(x) > 3) ++x;
 			if (x >= len) { active = false; continue; }
-			scode = rd.at(x); slen = 1;
-			ik = set_intv(ix, (int)scode); i = x + 1;
+			r3_start();
 			continue;
 		}
 		// ---- forward pass of an SMEM call, bwt.c:303-320
