@@ -602,8 +602,11 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 				HIP_TRY(hipStreamSynchronize(s));
 				uint64_t new_total = e->h_ctr.p[0];
 				CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
+				int fast16 = cap >= 16 ? 1 : 0;
+				if (fast16) hipLaunchKernelGGL(sort_compact16_kernel, dim3(grid_for(nb * 16, 256)), dim3(256), 0, s, e->d_out.p, e->d_cnt.p, cap,
+				                               e->d_mem_off.p + b0, nb, e->d_mems.p);
 				hipLaunchKernelGGL(sort_compact2_kernel, dim3(grid_for(nb, 128)), dim3(128), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
-				                   e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p);
+				                   e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p, fast16);
 				HIP_TRY(hipGetLastError());
 				total_mems = new_total;
 				continue;

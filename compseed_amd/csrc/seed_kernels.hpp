@@ -219,15 +219,30 @@ __global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2))
 
 // -------------------------------------------------------------------------------------------------------------------
 // ASCII -> nt4 (nst_nt4_table, FM_index/bntseq.c:46-63); bytes 0..4 pass through as CompSeed does (comp_seed.cpp:2259)
+__device__ __forceinline__ uint32_t nt4_of(uint32_t b)
+{
+	uint32_t u = b & 0xdfu; // fold case
+	uint32_t v = (u == 'A') ? 0u : (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : (b == '-') ? 5u : 4u;
+	return b <= 4 ? b : v;
+}
+// 16 bytes per lane when both buffers are 16-byte aligned (they are: hipMalloc / torch allocations), bytes otherwise
 __global__ void nt4_kernel(const uint8_t *in, uint8_t *out, uint64_t n)
 {
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	for (; i < n; i += stride) {
-		uint32_t b = in[i], u = b & 0xdfu; // fold case
-		uint32_t v = (u == 'A') ? 0u : (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : (b == '-') ? 5u : 4u;
-		out[i] = (uint8_t)(b <= 4 ? b : v);
+	uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+	uint64_t nv = ((((uintptr_t)in | (uintptr_t)out) & 15) == 0) ? n >> 4 : 0;
+	const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+	uint4 *out4 = reinterpret_cast<uint4 *>(out);
+	for (uint64_t i = tid; i < nv; i += stride) {
+		uint4 v = in4[i], o;
+		uint32_t *pv = &v.x, *po = &o.x;
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			uint32_t x = pv[w];
+			po[w] = nt4_of(x & 0xff) | nt4_of((x >> 8) & 0xff) << 8 | nt4_of((x >> 16) & 0xff) << 16 | nt4_of(x >> 24) << 24;
+		}
+		out4[i] = o;
 	}
+	for (uint64_t i = (nv << 4) + tid; i < n; i += stride) out[i] = (uint8_t)nt4_of(in[i]);
 }
 
 // per-read sort by info (comp_seed.cpp:2301) fused with the CSR compaction: rank every mem among its read's mems
