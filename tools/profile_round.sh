@@ -25,7 +25,7 @@ agg = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % tag, recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = "fwd_kernel" if "fwd_kernel" in k else "bwd_all_kernel" if "bwd_all" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
+        name = "fwd_kernel" if "fwd_kernel" in k else "bwd_all_kernel" if "bwd_all" in k else "bwd_wide_kernel" if "bwd_wide" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
         if name and r["Counter_Name"] == "FETCH_SIZE":
             agg[name] += float(r["Counter_Value"]); n[name] += 1
 out = {k: {"FETCH_SIZE_KiB_sum": v, "dispatches": n[k]} for k, v in agg.items()}
