@@ -366,10 +366,13 @@ static int scan_u64(cs_engine *e, const uint64_t *cnt, uint64_t *off, size_t n)
 __global__ void max_len_kernel(const uint64_t *off, int64_t n, unsigned long long *out_max, unsigned long long *bad)
 {
 	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= n) return;
-	uint64_t a = off[r], b = off[r + 1];
-	if (b < a) { atomicAdd(bad, 1ull); return; }
-	atomicMax(out_max, (unsigned long long)(b - a));
+	unsigned long long len = 0;
+	if (r < n) {
+		uint64_t a = off[r], b = off[r + 1];
+		if (b < a) atomicAdd(bad, 1ull); else len = b - a;
+	}
+	for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(len, o); len = other > len ? other : len; } // one atomic per wave
+	if ((threadIdx.x & 63) == 0) atomicMax(out_max, len);
 }
 __global__ void collect_overflow_kernel(const uint32_t *cnt, int64_t n, uint32_t cap, uint32_t first_read, uint32_t *list, unsigned long long *n_ovf)
 {

@@ -627,7 +627,7 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	uint32_t n = cnt[r];
-	if (skip_small && n <= 16) return; // done by sort_compact16_kernel
+	if (skip_small && n <= 64 && n <= cap) return; // done by sort_compact16_kernel
 	const OutMem *src = raw + (size_t)r * cap;
 	OutMem *dst = mems + mem_off[r];
 	if (n <= 16 && n <= cap) { // keys in registers, ranks by 16 x 16 compares, no re-reads
@@ -658,26 +658,40 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 		dst[rank] = ma;
 	}
 }
-// Fast form of the same for the bulk: 16 lanes per read (4 reads per wave), lane a owns mem a of the read.  Each mem is read
-// once (coalesced: 16 lanes x 32 B contiguous), keys travel by shuffle, and the lane writes its mem at its rank.  Reads
-// with more than 16 mems are left to sort_compact2_kernel (launched over the same range with skip_small set).
+// Fast form of the same for the bulk: 16 lanes per read (4 reads per wave).  Up to 16 mems: lane a owns mem a; 17..64 mems
+// (repeat-rich reads): lane a owns mems a, a+16, a+32, a+48.  Each mem is read once (coalesced: 16 lanes x 32 B contiguous),
+// keys travel by shuffle, and every lane writes its mems at their ranks.  Reads with more than 64 mems, or whose mems
+// spilled beyond `cap`, are left to sort_compact2_kernel (launched over the same range with skip_upto = 64).
 __global__ __launch_bounds__(256) void sort_compact16_kernel(const OutMem *raw, const uint32_t *cnt, uint32_t cap, const uint64_t *mem_off,
                                                              int64_t n_reads, OutMem *mems)
 {
 	const uint32_t lane = threadIdx.x & 63u, a = lane & 15u, gbase = lane & ~15u;
 	int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
 	uint32_t n = r < n_reads ? cnt[r] : 0;
-	bool mine = n <= 16 && a < n;
-	OutMem m = {0, 0, 0, ~0ull};
-	if (mine) m = raw[(size_t)r * cap + a];
-	uint64_t key = mine ? m.info : ~0ull;
-	uint32_t rank = 0;
+	if (n > 64 || n > cap) n = 0; // not ours
+	const OutMem *src = raw + (size_t)(r < n_reads ? r : 0) * cap;
+	OutMem m[4]; uint64_t key[4]; uint32_t rank[4] = {0, 0, 0, 0};
 #pragma unroll
-	for (int b = 0; b < 16; ++b) {
-		uint64_t kb = __shfl(key, (int)(gbase + b));
-		rank += (kb < key) || (kb == key && (uint32_t)b < a);
+	for (int s = 0; s < 4; ++s) {
+		uint32_t e = a + 16u * s;
+		key[s] = ~0ull;
+		if (e < n) { m[s] = src[e]; key[s] = m[s].info; }
 	}
-	if (mine) mems[mem_off[r] + rank] = m;
+	const int rounds = n > 48 ? 4 : n > 32 ? 3 : n > 16 ? 2 : 1; // group-uniform
+	for (int sb = 0; sb < rounds; ++sb) {
+#pragma unroll
+		for (int b = 0; b < 16; ++b) {
+			uint64_t kb = __shfl(sb == 0 ? key[0] : sb == 1 ? key[1] : sb == 2 ? key[2] : key[3], (int)(gbase + b));
+			uint32_t eb = (uint32_t)b + 16u * sb; // index of the mem whose key this is
+#pragma unroll
+			for (int s = 0; s < 4; ++s) rank[s] += (kb < key[s]) || (kb == key[s] && eb < a + 16u * s);
+		}
+	}
+	if (n) {
+		OutMem *dst = mems + mem_off[r];
+#pragma unroll
+		for (int s = 0; s < 4; ++s) if (a + 16u * s < n) dst[rank[s]] = m[s];
+	}
 }
 
 __global__ void ovf_keys_kernel(const OvfRec *ovf, uint64_t n, uint32_t *key, uint32_t *idx)
