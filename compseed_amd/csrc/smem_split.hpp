@@ -252,6 +252,14 @@ template <int DIR> struct BaseReader {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
+// the call that follows a finished round-1 call: next pivot = end of the longest forward match, ambiguous bases skipped
+__device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r, int ret)
+{
+	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
+	while (x < len && A.seq[rb + x] > 3) ++x;
+	return x < len ? ftask_pack(r, (uint32_t)x, 1, TK_ROUND1) : FTASK_NONE;
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 {
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 	uint4 *lep = nullptr;
 	unsigned long long my_q = 0, my_hits = 0;
 	WavePool P = {0, 0, false};
+	WaveOut O = {0, 0};
 	__shared__ uint4 sst[SST_ENTRIES];
 	sst_clear(sst);
 	const bool use_sst = A.sst != 0;
@@ -308,52 +317,58 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 			}
 		}
 		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
-		if (!active) continue;
-		// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
-		uint32_t b = i < len ? rd.at(i) : 4u;
-		Intv y = ik;
-		bool cached = false, cacheable = use_sst && b <= 3 && slen < SST2_K;
-		uint32_t ccode = scode << 2 | b;                    // the string extended by read base b
-		if (cacheable) cached = sst_get(sst, A.sst2, slen + 1, ccode, y);
-		if (b <= 3) {
-			++my_q;
-			if (cached) ++my_hits;
-			else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
-			scode = ccode; ++slen;                          // slen keeps counting; only values < SST2_K are looked at
+		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE; // forward tasks this lane spawns in this step
+		if (active) {
+			// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
+			uint32_t b = i < len ? rd.at(i) : 4u;
+			Intv y = ik;
+			bool cached = false, cacheable = use_sst && b <= 3 && slen < SST2_K;
+			uint32_t ccode = scode << 2 | b;                    // the string extended by read base b
+			if (cacheable) cached = sst_get(sst, A.sst2, slen + 1, ccode, y);
+			if (b <= 3) {
+				++my_q;
+				if (cached) ++my_hits;
+				else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
+				scode = ccode; ++slen;                          // slen keeps counting; only values < SST2_K are looked at
+			}
+			if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
+				if (b <= 3 && !(y.x2 < A.max_mem_intv && i - x >= A.min_seed_len)) { ik = y; ++i; }
+				else if (b > 3 && i >= len) active = false;
+				else {
+					if (b <= 3 && y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
+					x = i + 1; // restart behind the seed / the ambiguous base
+					while (x < len && rd.at(x) > 3) ++x;
+					if (x >= len) active = false; else r3_start();
+				}
+			} else { // ---- forward pass of an SMEM call, bwt.c:303-320
+				// A call at pivot 0 has a trivial backward sweep (bwt.c:325 starts at i = -1): its only SMEM is the longest
+				// forward match, so it needs no LEP list, no backward task, and finishes right here.
+				const bool pivot0 = x == 0;
+				const bool changed = b > 3 || y.x2 != ik.x2;            // read end (i == len), ambiguous base, or size change
+				const bool done = b > 3 || (y.x2 != ik.x2 && y.x2 < min_intv);
+				if (changed && !pivot0) lep[n++] = pack_lep(ik, (uint32_t)i);
+				if (!done) { ik = y; ++i; }
+				else {
+					if (pivot0) {
+						push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i);
+						if (kind == TK_ROUND1) push1 = chain_round1(A, r, i);
+					} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
+						uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
+						BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
+						A.bq[tslot] = bt;
+					}
+					active = false;
+				}
+			}
 		}
-
-		if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
-			if (b <= 3 && !(y.x2 < A.max_mem_intv && i - x >= A.min_seed_len)) { ik = y; ++i; continue; }
-			if (b > 3 && i >= len) { active = false; continue; }
-			if (b <= 3 && y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
-			x = i + 1; // restart behind the seed / the ambiguous base
-			while (x < len && rd.at(x) > 3) ++x;
-			if (x >= len) { active = false; continue; }
-			r3_start();
-			continue;
-		}
-		// ---- forward pass of an SMEM call, bwt.c:303-320
-		bool done = false;
-		if (b > 3) { lep[n++] = pack_lep(ik, (uint32_t)i); done = true; }       // read end (i == len) or ambiguous base
-		else if (y.x2 != ik.x2) { lep[n++] = pack_lep(ik, (uint32_t)i); done = y.x2 < min_intv; }
-		if (!done) { ik = y; ++i; continue; }
-		// hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
-		uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
-		BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
-		A.bq[tslot] = bt;
-		active = false;
+		wave_push<64>(O, push0 != FTASK_NONE, push0, A);
+		wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 	}
+	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
 }
 
-// the call that follows a finished round-1 call: next pivot = end of the longest forward match, ambiguous bases skipped
-__device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r, int ret)
-{
-	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
-	while (x < len && A.seq[rb + x] > 3) ++x;
-	return x < len ? ftask_pack(r, (uint32_t)x, 1, TK_ROUND1) : FTASK_NONE;
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 template <int G>
