@@ -15,6 +15,26 @@ with open(os.path.join(R, "gpurun_out", tag + "_kernel_stats.csv"), "w", newline
     w = csv.writer(o)
     for r in keep:
         r = list(r); r[0] = r[0][:110]; w.writerow(r)
+# wall span of the SMEM stage per pass from the kernel trace: first fwd_kernel start to last fwd/bwd kernel end.  (The round-3
+# fwd_kernel launch runs beside the first forward launch and bwd_wide_kernel beside bwd_all_kernel on their own streams, so
+# the summed durations exceed the span.)
+import json
+f = glob.glob("/tmp/prof_%s/**/*kernel_trace.csv" % tag, recursive=True)[0]
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))
+      if any(k in r["Kernel_Name"] for k in ("fwd_kernel", "bwd_all_kernel", "bwd_wide_kernel", "init_tasks_kernel"))]
+ev.sort()
+passes, cur = [], None
+for s0, e0, name in ev:
+    if "init_tasks" in name:
+        if cur: passes.append(cur)
+        cur = [None, None, 0, 0.0]
+        continue
+    if cur is None: continue
+    cur[0] = s0 if cur[0] is None else min(cur[0], s0); cur[1] = e0 if cur[1] is None else max(cur[1], e0); cur[2] += 1; cur[3] += (e0 - s0) / 1e6
+if cur: passes.append(cur)
+out = [{"span_ms": (p[1] - p[0]) / 1e6, "launches": p[2], "summed_kernel_ms": p[3]} for p in passes if p[0] is not None]
+json.dump({"passes": out}, open(os.path.join(R, "gpurun_out", tag + "_stage_span.json"), "w"), indent=1)
+print(json.dumps(out))
 PY
 if [ -n "$2" ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_$tag -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --check-reads 1000 > /tmp/pmc_$tag.json 2> /tmp/pmc_$tag.err
