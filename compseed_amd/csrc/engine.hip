@@ -90,6 +90,7 @@ struct cs_engine {
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
 	DevBuf<uint32_t> d_fsa32; DevBuf<uint64_t> d_fsa64; // full suffix array (one of the two)
+	DevBuf<uint32_t> d_text2, d_isa32; DevBuf<uint64_t> d_isa64; // text mode: 2-bit text + inverse suffix array
 	// inputs
 	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
 	// SMEM stage
@@ -277,6 +278,33 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		}
 	}
 
+	// text mode (smem_split.hpp): the 2-bit text and the inverse suffix array, derived from the full suffix array
+	ix.text2 = nullptr; ix.isa32 = nullptr; ix.isa64 = nullptr;
+	{
+		const char *tm = getenv("CS_TEXT_MODE");
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		uint64_t rows = v->seq_len + 1;
+		size_t need = (size_t)rows * (ix.fsa32 ? 4 : 8) + (size_t)v->seq_len + (size_t)v->seq_len / 4 + ((size_t)24 << 30);
+		if ((!tm || atoi(tm) != 0) && (ix.fsa32 || ix.fsa64) && need < free_b) {
+			DevBuf<uint8_t> tbytes;
+			CS_TRY(tbytes.reserve((size_t)v->seq_len + 64));
+			CS_TRY(e->d_text2.reserve((size_t)((v->seq_len + 15) >> 4) + 16));
+			unsigned grid = (unsigned)std::min<uint64_t>((rows + 255) / 256, 1u << 22);
+			if (ix.fsa32) {
+				CS_TRY(e->d_isa32.reserve((size_t)rows + 16));
+				hipLaunchKernelGGL(text_isa_fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, e->stream, ix, ix.fsa32, tbytes.p, e->d_isa32.p);
+			} else {
+				CS_TRY(e->d_isa64.reserve((size_t)rows + 16));
+				hipLaunchKernelGGL(text_isa_fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, e->stream, ix, ix.fsa64, tbytes.p, e->d_isa64.p);
+			}
+			hipLaunchKernelGGL(text_pack_kernel, dim3(grid), dim3(256), 0, e->stream, tbytes.p, v->seq_len, e->d_text2.p);
+			HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
+			tbytes.release();
+			ix.text2 = e->d_text2.p; ix.isa32 = e->d_isa32.p; ix.isa64 = e->d_isa64.p;
+		}
+		if (verbose) { fprintf(stderr, "[cs_engine] text mode: %s\n", ix.text2 ? "on" : "off"); fflush(stderr); }
+	}
 	// round-3 jump table (smem_split.hpp): every 15-mer, 17 GB (13: 1 GB, measured 2 % slower); CS_JUMP_K = 0 disables
 	{
 		int jk = 15;
@@ -314,7 +342,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();

@@ -34,6 +34,11 @@ struct DevIndex {
 	// gather instead of a walk of up to sa_intv-1 dependent Occ reads.  Null when disabled / out of memory.
 	const uint32_t *fsa32;
 	const uint64_t *fsa64;
+	// "text mode" for unique matches (smem_split.hpp): the text itself, 2 bits per base (16 bases per word, base j in bits
+	// 2j..2j+1), and the inverse suffix array.  Null when disabled / out of memory.
+	const uint32_t *text2;
+	const uint32_t *isa32;
+	const uint64_t *isa64;
 };
 
 struct Intv { uint64_t x0, x1, x2; };
@@ -235,6 +240,33 @@ __device__ __forceinline__ uint64_t sa_direct(const DevIndex &ix, uint64_t k)
 {
 	if (k == 0) return ~0ull; // sa[0] = -1 (bwt.c:83)
 	return ix.fsa32 ? (uint64_t)ix.fsa32[k] : ix.fsa64[k];
+}
+
+__device__ __forceinline__ uint64_t isa_direct(const DevIndex &ix, uint64_t pos) { return ix.isa32 ? (uint64_t)ix.isa32[pos] : ix.isa64[pos]; }
+
+// one-time preparation of the text-mode arrays from the full suffix array: T[SA[r] - 1] is the BWT character of row r
+template <typename T>
+__global__ void text_isa_fill_kernel(const DevIndex ix, const T *fsa, uint8_t *tbytes, T *isa)
+{
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= ix.seq_len; r += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t s = (uint64_t)fsa[r];
+		isa[s] = (T)r;
+		if (r == ix.primary) continue; // the row of the whole text: its BWT character is the sentinel
+		uint64_t row = r - (r > ix.primary);
+		Block b = load_block(ix, row >> OCC_SHIFT);
+		uint32_t p = (uint32_t)row & OCC_MASK, w = p >> 5, bit = p & 31;
+		uint32_t lo = w == 0 ? b.pl.x : b.pl.y, hi = w == 0 ? b.pl.z : b.pl.w;
+		tbytes[s - 1] = (uint8_t)(((lo >> bit) & 1u) | (((hi >> bit) & 1u) << 1));
+	}
+}
+__global__ void text_pack_kernel(const uint8_t *tbytes, uint64_t n, uint32_t *text2)
+{
+	uint64_t nw = (n + 15) >> 4;
+	for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t v = 0;
+		for (int j = 0; j < 16; ++j) { uint64_t p = w * 16 + j; if (p < n) v |= (uint32_t)(tbytes[p] & 3) << (2 * j); }
+		text2[w] = v;
+	}
 }
 
 // bwt_sa (bwt.c:86-96)

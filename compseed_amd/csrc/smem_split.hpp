@@ -29,7 +29,7 @@
 
 namespace csd {
 
-enum : uint32_t { TK_ROUND1 = 0, TK_ROUND2 = 1, TK_ROUND3 = 2, TK_NOP = 3 };
+enum : uint32_t { TK_ROUND1 = 0, TK_ROUND2 = 1, TK_ROUND3 = 2, TK_NOP = 3, TK_TEXT = 4 /* fwd_kernel-internal: a round-1 call in text mode */ };
 
 // forward task, 8 bytes: read | pivot | min_intv | kind
 __device__ __host__ __forceinline__ uint64_t ftask_pack(uint32_t r, uint32_t x, uint32_t min_intv, uint32_t kind)
@@ -261,7 +261,7 @@ __device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r,
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
+__global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 {
 	const DevIndex &ix = A.ix;
 	bool active = false;
@@ -277,6 +277,13 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 	sst_clear(sst);
 	const bool use_sst = A.sst != 0;
 	int slen = 0; uint32_t scode = 0; // the string matched so far, while it is short enough for the SST
+	// Text mode.  Once the forward match of an SMEM call occurs exactly once, every further bwt_extend only re-ranks that one
+	// occurrence: its size stays 1 until the read and the text disagree (bwt.c:309-316 pushes nothing in between).  So the
+	// lane looks the occurrence's text position up in the suffix array once, compares the read against the 2-bit text eight
+	// bases per iteration without touching the index, and at the end takes the reverse-strand coordinate from the inverse
+	// suffix array (the forward coordinate of a unique match does not move).  Two random reads replace ~80 per read.
+	const bool text_on = use_sst && ix.text2 != nullptr;
+	uint32_t tw = 0; // text mode (kind == TK_TEXT): the 16 text bases around the cursor; the cursor itself lives in ik.x1
 	const int jump_k = (use_sst && A.jump && A.jump_k <= A.min_seed_len) ? A.jump_k : 0;
 	// start a round-3 segment at x: through the jump table when the next jump_k bases are all A/C/G/T, else base by base
 	auto r3_start = [&]() {
@@ -319,46 +326,69 @@ __global__ __launch_bounds__(BLOCK) void fwd_kernel(const SplitArgs A)
 		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
 		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE; // forward tasks this lane spawns in this step
 		if (active) {
-			// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
-			uint32_t b = i < len ? rd.at(i) : 4u;
-			Intv y = ik;
-			bool cached = false, cacheable = use_sst && b <= 3 && slen < SST2_K;
-			uint32_t ccode = scode << 2 | b;                    // the string extended by read base b
-			if (cacheable) cached = sst_get(sst, A.sst2, slen + 1, ccode, y);
-			if (b <= 3) {
-				++my_q;
-				if (cached) ++my_hits;
-				else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
-				scode = ccode; ++slen;                          // slen keeps counting; only values < SST2_K are looked at
-			}
-			if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
-				if (b <= 3 && !(y.x2 < A.max_mem_intv && i - x >= A.min_seed_len)) { ik = y; ++i; }
-				else if (b > 3 && i >= len) active = false;
-				else {
-					if (b <= 3 && y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
-					x = i + 1; // restart behind the seed / the ambiguous base
-					while (x < len && rd.at(x) > 3) ++x;
-					if (x >= len) active = false; else r3_start();
+			bool fin = false; // the forward pass of an SMEM call ends in this iteration with ik = [x, i)
+			if (kind == TK_TEXT) {
+				uint64_t tpos = ik.x1;
+				for (int q = 0; q < 8; ++q) {
+					uint32_t b = i < len ? rd.at(i) : 4u;
+					if (b > 3) { fin = true; break; }                      // read end or ambiguous base: no extension is attempted
+					++my_q; ++my_hits;                                     // the bwt_extend the reference performs here
+					uint32_t tb = tpos < ix.seq_len ? (tw >> ((uint32_t)(tpos & 15) << 1)) & 3u : 4u;
+					if (tb != b) { fin = true; break; }                    // mismatch or text end: that extension returns size 0
+					++i; ++tpos;
+					if ((tpos & 15) == 0) tw = ix.text2[tpos >> 4];        // padded: readable up to and including seq_len
 				}
-			} else { // ---- forward pass of an SMEM call, bwt.c:303-320
+				ik.x1 = tpos;
+				if (fin) { ik.x1 = isa_direct(ix, ix.seq_len - tpos); kind = TK_ROUND1; } // rank of the reverse complement of [x, i)
+			} else {
+				// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
+				uint32_t b = i < len ? rd.at(i) : 4u;
+				Intv y = ik;
+				bool cached = false, cacheable = use_sst && b <= 3 && slen < SST2_K;
+				uint32_t ccode = scode << 2 | b;                    // the string extended by read base b
+				if (cacheable) cached = sst_get(sst, A.sst2, slen + 1, ccode, y);
+				if (b <= 3) {
+					++my_q;
+					if (cached) ++my_hits;
+					else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
+					scode = ccode; ++slen;                          // slen keeps counting; only values < SST2_K are looked at
+				}
+				if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
+					if (b <= 3 && !(y.x2 < A.max_mem_intv && i - x >= A.min_seed_len)) { ik = y; ++i; }
+					else if (b > 3 && i >= len) active = false;
+					else {
+						if (b <= 3 && y.x2 > 0) emit_mem(A, r, y, (uint32_t)x, (uint32_t)(i + 1));
+						x = i + 1; // restart behind the seed / the ambiguous base
+						while (x < len && rd.at(x) > 3) ++x;
+						if (x >= len) active = false; else r3_start();
+					}
+				} else { // ---- forward pass of an SMEM call, bwt.c:303-320
+					const bool changed = b > 3 || y.x2 != ik.x2;            // read end (i == len), ambiguous base, or size change
+					fin = b > 3 || (y.x2 != ik.x2 && y.x2 < min_intv);
+					if (changed && !fin && x != 0) lep[n++] = pack_lep(ik, (uint32_t)i);
+					if (!fin) {
+						ik = y; ++i;
+						if (text_on && ik.x2 == 1 && kind == TK_ROUND1) { // unique from here on: continue on the text
+							kind = TK_TEXT;
+							ik.x1 = sa_direct(ix, ik.x0) + (uint64_t)(i - x);  // text cursor: the base that has to equal read base i
+							tw = ix.text2[ik.x1 >> 4];
+						}
+					}
+				}
+			}
+			if (fin) { // ik = the longest forward match [x, i): the last LEP (bwt.c:307/315/320)
 				// A call at pivot 0 has a trivial backward sweep (bwt.c:325 starts at i = -1): its only SMEM is the longest
 				// forward match, so it needs no LEP list, no backward task, and finishes right here.
-				const bool pivot0 = x == 0;
-				const bool changed = b > 3 || y.x2 != ik.x2;            // read end (i == len), ambiguous base, or size change
-				const bool done = b > 3 || (y.x2 != ik.x2 && y.x2 < min_intv);
-				if (changed && !pivot0) lep[n++] = pack_lep(ik, (uint32_t)i);
-				if (!done) { ik = y; ++i; }
-				else {
-					if (pivot0) {
-						push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i);
-						if (kind == TK_ROUND1) push1 = chain_round1(A, r, i);
-					} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
-						uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
-						BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
-						A.bq[tslot] = bt;
-					}
-					active = false;
+				if (x == 0) {
+					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i);
+					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i);
+				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
+					lep[n++] = pack_lep(ik, (uint32_t)i);
+					uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
+					BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
+					A.bq[tslot] = bt;
 				}
+				active = false;
 			}
 		}
 		wave_push<64>(O, push0 != FTASK_NONE, push0, A);
