@@ -91,6 +91,7 @@ struct cs_engine {
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
 	DevBuf<uint32_t> d_fsa32; DevBuf<uint64_t> d_fsa64; // full suffix array (one of the two)
 	DevBuf<uint32_t> d_text2, d_isa32; DevBuf<uint64_t> d_isa64; // text mode: 2-bit text + inverse suffix array
+	DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
 	// inputs
 	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
 	// SMEM stage
@@ -305,6 +306,32 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		}
 		if (verbose) { fprintf(stderr, "[cs_engine] text mode: %s\n", ix.text2 ? "on" : "off"); fflush(stderr); }
 	}
+	// re-seeding from the text (smem_split.hpp, r2text_kernel): capped LCP array and repeat-length array, 1 byte per row each
+	ix.lcp = nullptr; ix.rep = nullptr;
+	{
+		const char *rt = getenv("CS_R2_TEXT");
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		size_t need = (size_t)v->seq_len * 2 + ((size_t)24 << 30);
+		if ((!rt || atoi(rt) != 0) && ix.text2 && need < free_b) {
+			uint64_t rows = v->seq_len + 1;
+			CS_TRY(e->d_lcp.reserve((size_t)rows + 64)); CS_TRY(e->d_rep.reserve((size_t)rows + 64));
+			unsigned grid = (unsigned)std::min<uint64_t>((rows + 256) / 256, 1u << 22);
+			if (ix.fsa32) {
+				hipLaunchKernelGGL(lcp_fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, e->stream, ix, ix.fsa32, e->d_lcp.p);
+				hipLaunchKernelGGL(rep_fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, e->stream, ix, ix.fsa32, (const uint8_t *)e->d_lcp.p, e->d_rep.p);
+			} else {
+				hipLaunchKernelGGL(lcp_fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, e->stream, ix, ix.fsa64, e->d_lcp.p);
+				hipLaunchKernelGGL(rep_fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, e->stream, ix, ix.fsa64, (const uint8_t *)e->d_lcp.p, e->d_rep.p);
+			}
+			HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
+			ix.lcp = e->d_lcp.p; ix.rep = e->d_rep.p;
+		}
+		if (verbose) {
+			HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+			fprintf(stderr, "[cs_engine] re-seeding from the text: %s; device memory free %.1f of %.1f GB\n", ix.rep ? "on" : "off", free_b / 1e9, total_b / 1e9); fflush(stderr);
+		}
+	}
 	// round-3 jump table (smem_split.hpp): every 15-mer, 17 GB (13: 1 GB, measured 2 % slower); CS_JUMP_K = 0 disables
 	{
 		int jk = 15;
@@ -342,7 +369,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
@@ -491,6 +518,8 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	uint64_t chunk = std::max<uint64_t>(4096, e->lep_arena_bytes / ((size_t)stride * sizeof(uint4)));
 	chunk = std::min<uint64_t>(chunk, fq_cap);
 	CS_TRY(e->d_fqA.reserve(fq_cap)); CS_TRY(e->d_fqB.reserve(fq_cap)); CS_TRY(e->d_fqR.reserve((size_t)nb + 1));
+	const bool r2text = e->ix.rep != nullptr && par->sst_mode != 0;
+	if (r2text) { CS_TRY(e->d_auxA.reserve(fq_cap)); CS_TRY(e->d_auxB.reserve(fq_cap)); }
 	CS_TRY(e->d_bq.reserve(chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
 	CS_TRY(e->d_ovfrec.reserve(ovf_cap));
 	unsigned long long *C = e->d_sctr.p, *H = e->h_sctr.p; // [0] task ctr [1] next-queue length [2..5] backward queues [6] overflow mems [7] error [8] queries
@@ -510,7 +539,8 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.fq_cap = fq_cap; A.n_f_next = C + 1;
 
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;
-	A.fq = cur; A.n_f = 0; A.fq_next = nxt;
+	uint64_t *aux_cur = r2text ? e->d_auxA.p : nullptr, *aux_nxt = r2text ? e->d_auxB.p : nullptr;
+	A.fq = cur; A.n_f = 0; A.fq_next = nxt; A.aux_next = aux_nxt;
 	HIP_TRY(hipEventRecord(e->ev[0], s));
 	hipLaunchKernelGGL(init_tasks_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, A, cur, e->d_fqR.p);
 	// Round 3 depends on nothing: it runs on a low-priority second stream and fills the tails of the launches below.
@@ -527,7 +557,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	}
 	uint64_t n_f = (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
-		A.fq_next = nxt;
+		A.fq_next = nxt; A.aux_next = aux_nxt;
 		for (uint64_t c0 = 0; c0 < n_f; ) {
 			uint64_t cn = std::min<uint64_t>(chunk, n_f - c0);
 			A.fq = cur + c0; A.n_f = cn;
@@ -552,12 +582,17 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			}
 			c0 += cn;
 		}
+		if (r2text) { // re-seeding calls of unique SMEMs pushed by this iteration: answer from the text what the text can answer
+			hipLaunchKernelGGL(r2text_kernel, dim3((unsigned)e->n_cu * 8), dim3(256), 0, s, A, nxt, (const uint64_t *)aux_nxt,
+			                   (const unsigned long long *)(C + 1), C + 11, C + 12);
+			HIP_TRY(hipGetLastError());
+		}
 		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); return 1; }
 		n_f = H[1];
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
-		std::swap(cur, nxt);
+		std::swap(cur, nxt); std::swap(aux_cur, aux_nxt);
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
 	if (r3_async) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
@@ -567,6 +602,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 	e->st.seed_kernel_launches++;
 	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8] - H[9]; // calls = queries not answered by the on-device SST
+	e->st.reseed_text_calls += H[11]; e->st.reseed_index_calls += H[12];
 	*n_ovf_out = H[6];
 	return CS_OK;
 }

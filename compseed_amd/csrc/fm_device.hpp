@@ -39,6 +39,11 @@ struct DevIndex {
 	const uint32_t *text2;
 	const uint32_t *isa32;
 	const uint64_t *isa64;
+	// Re-seeding from the text (smem_split.hpp, r2text_kernel): lcp[r] = min(255, LCP(suffix of row r-1, suffix of row r))
+	// for rows 1..seq_len (lcp[0] = lcp[seq_len+1] = 0), and rep[p] = max(lcp[ISA[p]], lcp[ISA[p]+1]) = length of the longest
+	// substring starting at text position p that occurs at least twice (capped at 255).  Null when disabled.
+	const uint8_t *lcp;
+	const uint8_t *rep;
 };
 
 struct Intv { uint64_t x0, x1, x2; };
@@ -266,6 +271,42 @@ __global__ void text_pack_kernel(const uint8_t *tbytes, uint64_t n, uint32_t *te
 		uint32_t v = 0;
 		for (int j = 0; j < 16; ++j) { uint64_t p = w * 16 + j; if (p < n) v |= (uint32_t)(tbytes[p] & 3) << (2 * j); }
 		text2[w] = v;
+	}
+}
+
+// 32 text bases from position pos on (2 bits each, base j in bits 2j..2j+1); the text buffer is padded
+__device__ __forceinline__ uint64_t text_win(const DevIndex &ix, uint64_t pos)
+{
+	const uint64_t *t = reinterpret_cast<const uint64_t *>(ix.text2);
+	uint64_t k = pos >> 5; uint32_t sh = (uint32_t)(pos & 31) << 1;
+	uint64_t w0 = t[k], w1 = t[k + 1];
+	return sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+}
+// length of the common prefix of the suffixes at text positions a and b, capped (the sentinel matches nothing)
+__device__ __forceinline__ uint32_t text_lcp(const DevIndex &ix, uint64_t a, uint64_t b, uint32_t cap)
+{
+	uint64_t room = ix.seq_len - (a > b ? a : b);
+	uint32_t lim = room < cap ? (uint32_t)room : cap, l = 0;
+	while (l < lim) {
+		uint64_t x = text_win(ix, a + l) ^ text_win(ix, b + l);
+		uint32_t m = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 1 : 32u;
+		l += m;
+		if (m < 32) break;
+	}
+	return l < lim ? l : lim;
+}
+template <typename T>
+__global__ void lcp_fill_kernel(const DevIndex ix, const T *fsa, uint8_t *lcp)
+{
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= ix.seq_len + 1; r += (uint64_t)gridDim.x * blockDim.x)
+		lcp[r] = (r == 0 || r > ix.seq_len) ? 0 : (uint8_t)text_lcp(ix, (uint64_t)fsa[r - 1], (uint64_t)fsa[r], 255u);
+}
+template <typename T>
+__global__ void rep_fill_kernel(const DevIndex ix, const T *fsa, const uint8_t *lcp, uint8_t *rep)
+{
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= ix.seq_len; r += (uint64_t)gridDim.x * blockDim.x) {
+		uint8_t a = lcp[r], b = lcp[r + 1];
+		rep[(uint64_t)fsa[r]] = a > b ? a : b; // row 0 (the empty suffix) writes rep[seq_len] = 0
 	}
 }
 

@@ -53,6 +53,7 @@ struct SplitArgs {
 	uint64_t  max_mem_intv;
 	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
 	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
+	uint64_t *aux_next;                               // side word of fq_next[slot] for re-seeding calls (r2text_kernel), or null
 	BTask    *bq;                                     // backward task of forward task t: bq[t] (no atomics: 1:1)
 	uint4    *lep; uint32_t lep_stride;               // LEP list of forward task t: lep + t*lep_stride
 	unsigned long long *task_ctr;
@@ -74,21 +75,26 @@ __device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const I
 		if (s < A.ovf_cap) { OvfRec o = {m, r, 0}; A.ovf[s] = o; } else atomicMax(A.err, 1ull);
 	}
 }
-__device__ __forceinline__ void push_ftask(const SplitArgs &A, uint64_t t) // one atomic per task: rare paths only
+__device__ __forceinline__ void push_ftask(const SplitArgs &A, uint64_t t, uint64_t aux = ~0ull) // one atomic per task: rare paths only
 {
 	unsigned long long s = atomicAdd(A.n_f_next, 1ull);
-	if (s < A.fq_cap) A.fq_next[s] = t; else atomicMax(A.err, 2ull);
+	if (s < A.fq_cap) { A.fq_next[s] = t; if (aux != ~0ull) A.aux_next[s] = aux; } else atomicMax(A.err, 2ull);
 }
 constexpr uint64_t FTASK_NONE = ~0ull; // kind bits = TK_NOP
+constexpr uint64_t AUX_NONE = ~0ull;
 // an SMEM of a round-1/2 call: length filter (bwamem.c:232,246); returns the re-seeding call a round-1 SMEM triggers
-// (bwamem.c:241-249) or FTASK_NONE
-__device__ __forceinline__ uint64_t emit_smem(const SplitArgs &A, uint32_t r, uint32_t kind, const Intv &v, int beg, uint32_t end)
+// (bwamem.c:241-249) or FTASK_NONE.  aux: for the re-seeding call of a UNIQUE SMEM (min_intv 2), what r2text_kernel needs
+// to find the SMEM in the text: x0 | beg << 37 | parity(beg + end) << 53.
+__device__ __forceinline__ uint64_t emit_smem(const SplitArgs &A, uint32_t r, uint32_t kind, const Intv &v, int beg, uint32_t end, uint64_t &aux)
 {
 	int len = (int)end - beg;
+	aux = AUX_NONE;
 	if (len < A.min_seed_len) return FTASK_NONE;
 	emit_mem(A, r, v, (uint32_t)beg, end);
-	if (kind == TK_ROUND1 && len >= A.split_len && v.x2 <= A.split_width)
+	if (kind == TK_ROUND1 && len >= A.split_len && v.x2 <= A.split_width) {
+		if (v.x2 == 1 && A.aux_next) aux = v.x0 | (uint64_t)beg << 37 | (uint64_t)(((uint32_t)beg + end) & 1u) << 53;
 		return ftask_pack(r, (uint32_t)(beg + (int)end) >> 1, (uint32_t)v.x2 + 1, TK_ROUND2);
+	}
 	return FTASK_NONE;
 }
 
@@ -199,7 +205,7 @@ __device__ __forceinline__ bool pool_take(WavePool &P, bool want, unsigned long 
 // (ballot + popcount); slots left over when the wave moves on are filled with no-op tasks.
 struct WaveOut { uint64_t cur, end; };
 template <int RES>
-__device__ __forceinline__ void wave_push(WaveOut &O, bool want, uint64_t task, const SplitArgs &A)
+__device__ __forceinline__ void wave_push(WaveOut &O, bool want, uint64_t task, const SplitArgs &A, uint64_t aux = AUX_NONE)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	uint64_t m = __ballot(want);
@@ -216,7 +222,7 @@ __device__ __forceinline__ void wave_push(WaveOut &O, bool want, uint64_t task, 
 		O.cur = base; O.end = base + RES;
 	}
 	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-	if (want) A.fq_next[O.cur + rank] = task;
+	if (want) { A.fq_next[O.cur + rank] = task; if (aux != AUX_NONE) A.aux_next[O.cur + rank] = aux; }
 	O.cur += cnt;
 }
 __device__ __forceinline__ void wave_push_finish(WaveOut &O, const SplitArgs &A)
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 			}
 		}
 		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
-		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE; // forward tasks this lane spawns in this step
+		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE; // forward tasks this lane spawns in this step
 		if (active) {
 			bool fin = false; // the forward pass of an SMEM call ends in this iteration with ik = [x, i)
 			if (kind == TK_TEXT) {
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 				// A call at pivot 0 has a trivial backward sweep (bwt.c:325 starts at i = -1): its only SMEM is the longest
 				// forward match, so it needs no LEP list, no backward task, and finishes right here.
 				if (x == 0) {
-					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i);
+					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i, aux0);
 					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i);
 				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
 					lep[n++] = pack_lep(ik, (uint32_t)i);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 				active = false;
 			}
 		}
-		wave_push<64>(O, push0 != FTASK_NONE, push0, A);
+		wave_push<64>(O, push0 != FTASK_NONE, push0, A, aux0);
 		wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 	}
 	wave_push_finish(O, A);
@@ -468,14 +474,14 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 			}
 		}
 		if (exhausted && avail_m == 0 && __ballot(active) == 0) break; // wave-uniform exit
-		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE; // forward tasks this lane spawns in this step
+		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE; // forward tasks this lane spawns in this step
 		if (active) {
 			uint32_t b = i < 0 ? 4u : rd.at(i);
 			uint64_t live_m = __ballot(live) & gmask;
 			int first = __ffsll((long long)live_m) - 1; // the longest live match of the group
 			bool end_call = false;
 			if (b > 3) { // read start or ambiguous base (bwt.c:326): every live match stops; only the longest can be new
-				if ((int)lane == first && (nm == 0 || i + 1 < last_start)) push0 = emit_smem(A, r, kind, e, i + 1, pend);
+				if ((int)lane == first && (nm == 0 || i + 1 < last_start)) push0 = emit_smem(A, r, kind, e, i + 1, pend, aux0);
 				end_call = true;
 			} else {
 				Intv y = e;
@@ -493,7 +499,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				// bwt.c:328-336: the first live match is an SMEM if it stops here (nothing longer survived) and is not contained
 				bool first_stops = !((cand_m >> first) & 1ull);
 				if (first_stops && (nm == 0 || i + 1 < last_start)) {
-					if ((int)lane == first) push0 = emit_smem(A, r, kind, e, i + 1, pend);
+					if ((int)lane == first) push0 = emit_smem(A, r, kind, e, i + 1, pend, aux0);
 					++nm; last_start = i + 1;
 				}
 				// bwt.c:337-340: keep a surviving match unless its size equals that of the previous surviving one
@@ -509,7 +515,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				active = false;
 			}
 		}
-		wave_push<32>(O, push0 != FTASK_NONE, push0, A);
+		wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
 		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
 	}
 }
@@ -546,7 +552,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 		int n = bt.n, lo = 0, nm = 0, last_start = 0;
 		for (int i = (int)bt.x - 1; i >= -1; --i) {
 			uint32_t b = i < 0 ? 4u : A.seq[rb + i];
-			int w = n; bool first_done = false, have_prev = false; uint64_t prev_carry = 0, push0 = FTASK_NONE;
+			int w = n; bool first_done = false, have_prev = false; uint64_t prev_carry = 0, push0 = FTASK_NONE, aux0 = AUX_NONE;
 			for (int top = n; top > lo; top -= 64) {
 				int j = top - 1 - (int)lane; bool valid = j >= lo;
 				Intv p = {0, 0, 0}; uint32_t pend = 0;
@@ -558,7 +564,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 				if (!first_done) { // lane 0 of the first chunk holds the longest live match (bwt.c:328-336)
 					first_done = true;
 					if (!(cand_m & 1ull) && (nm == 0 || i + 1 < last_start)) {
-						if (lane == 0) push0 = emit_smem(A, r, kind, p, i + 1, pend);
+						if (lane == 0) push0 = emit_smem(A, r, kind, p, i + 1, pend, aux0);
 						++nm; last_start = i + 1;
 					}
 				}
@@ -573,7 +579,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 				if (cand_m) { have_prev = true; prev_carry = __shfl(y.x2, 63 - __clzll((long long)cand_m)); }
 			}
 			__threadfence_block(); // the compacted list is read back by other lanes of this wave in the next step
-			wave_push<32>(O, push0 != FTASK_NONE, push0, A);
+			wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
 			if (w == n) break;
 			lo = w;
 		}
@@ -645,8 +651,8 @@ __global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n
 				if (b <= 3) { y = extend1<true>(ix, p, (int)b); ++my_q; }
 				if (b > 3 || y.x2 < min_intv) {
 					if (!kept && (nm == 0 || i + 1 < last_start)) {
-						uint64_t t2 = emit_smem(A, r, kind, p, i + 1, pend);
-						if (t2 != FTASK_NONE) push_ftask(A, t2);
+						uint64_t ax, t2 = emit_smem(A, r, kind, p, i + 1, pend, ax);
+						if (t2 != FTASK_NONE) push_ftask(A, t2, ax);
 						++nm; last_start = i + 1;
 					}
 				} else if (!kept || y.x2 != last_kept) { lep[--w] = pack_lep(y, pend); kept = true; last_kept = y.x2; }
@@ -657,6 +663,91 @@ __global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n
 		if (kind == TK_ROUND1) { uint64_t t2 = chain_round1(A, r, bt.ret); if (t2 != FTASK_NONE) push_ftask(A, t2); }
 	}
 	atomicAdd(A.n_queries, my_q);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Re-seeding from the text.
+//
+// A round-1 SMEM [beg, end) with a single occurrence triggers bwt_smem1a(pivot = (beg+end)/2, min_intv = 2)
+// (bwamem.c:241-249): all maximal substrings through the pivot that occur at least twice.  On the FM index that is a
+// forward pass plus a triangular backward sweep, ~150 extensions, and for most reads it finds nothing of min_seed_len.
+// But inside [beg, end) the read IS the text at the SMEM's position P = SA[x0], and "occurs at least twice" is a property
+// of the text alone: the substring of length l at text position p is repeated iff l <= rep[p] (fm_device.hpp).  So with
+// e(q) = q + rep[q] the sweep of bwt.c:303-345 reads off directly:
+//   * forward pass from the pivot p: longest match with >= 2 occurrences ends at e(p);
+//   * backward step to start q: the longest surviving end is e(q) (never larger than e(q+1));
+//   * [q, e(q)) is reported when it does not survive the next step, e(q-1) < e(q), i.e. rep[q-1] <= rep[q];
+//   * the sweep is over when e(q) <= p.
+// The bi-interval of a reported substring comes from the inverse suffix array and a short walk over lcp[] to the ends of
+// its suffix-array interval (forward strand and reverse-complement strand).
+// This only holds while the substrings stay inside [beg, end), where read and text agree: if a candidate reaches either
+// end of the SMEM, a capped value (255) turns up, or an interval walk gets long, nothing is emitted and the call stays
+// in the queue for fwd_kernel / bwd_all_kernel.  So the result is the reference's either way; only the cost differs.
+struct RepReader { // rep[] bytes around a moving text position, one aligned 8-byte load per 8 positions
+	const uint8_t *base; uint64_t wk, w;
+	__device__ __forceinline__ uint32_t at(uint64_t pos)
+	{
+		uint64_t k = pos >> 3;
+		if (k != wk) { wk = k; w = *reinterpret_cast<const uint64_t *>(base + (k << 3)); }
+		return (uint32_t)(w >> ((pos & 7) << 3)) & 0xffu;
+	}
+};
+// bi-interval of the repeated substring of length v at text position pos (v <= 254, so the capped lcp[] decides exactly)
+__device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out)
+{
+	constexpr int MAX_WALK = 48;
+	uint64_t lo = isa_direct(ix, pos), hi = lo, lo2 = isa_direct(ix, ix.seq_len - (pos + v));
+	int steps = 0;
+	while (ix.lcp[lo] >= v) { --lo; if (++steps > MAX_WALK) return false; }
+	while (ix.lcp[hi + 1] >= v) { ++hi; if (++steps > MAX_WALK) return false; }
+	while (ix.lcp[lo2] >= v) { --lo2; if (++steps > 2 * MAX_WALK) return false; }
+	out.x0 = lo; out.x1 = lo2; out.x2 = hi - lo + 1;
+	return true;
+}
+__device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint64_t x0, int beg, int end, int pivot)
+{
+	const DevIndex &ix = A.ix;
+	const int len = end - beg, po = pivot - beg, k = A.min_seed_len;
+	if (k < 2 || po > 4096) return false;
+	const uint64_t P = sa_direct(ix, x0); // text position of read base `beg`
+	RepReader R = {ix.rep, ~0ull, 0};
+	int ne = 0, o0 = 0, v0 = 0, o1 = 0, v1 = 0; // at most two reported substrings; more: leave it to the index
+	int o = po, v = (int)R.at(P + (uint64_t)o);
+	for (;;) {
+		if (v == 255 || v == 0 || o + v >= len) return false; // capped / degenerate / reaches the end of the SMEM
+		if (o + v <= po) break;                               // no longer through the pivot: the sweep is over
+		if (o == 0) return false;                             // still through the pivot at the SMEM's start: may extend beyond it
+		int vp = (int)R.at(P + (uint64_t)o - 1);
+		if (vp == 255) return false;
+		if (vp <= v && v >= k) {
+			if (ne == 0) { o0 = o; v0 = v; } else if (ne == 1) { o1 = o; v1 = v; } else return false;
+			++ne;
+		}
+		--o; v = vp;
+	}
+	Intv i0 = {0, 0, 0}, i1 = {0, 0, 0};
+	if (ne > 0 && !text_interval(ix, P + (uint64_t)o0, (uint32_t)v0, i0)) return false;
+	if (ne > 1 && !text_interval(ix, P + (uint64_t)o1, (uint32_t)v1, i1)) return false;
+	if (ne > 0) emit_mem(A, r, i0, (uint32_t)(beg + o0), (uint32_t)(beg + o0 + v0));
+	if (ne > 1) emit_mem(A, r, i1, (uint32_t)(beg + o1), (uint32_t)(beg + o1 + v1));
+	return true;
+}
+// one lane per slot of the next forward queue; answered calls are replaced by no-ops
+__global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, uint64_t *fq, const uint64_t *aux, const unsigned long long *n_ptr,
+                                                     unsigned long long *n_done, unsigned long long *n_left)
+{
+	uint64_t n = *n_ptr; if (n > A.fq_cap) n = A.fq_cap;
+	unsigned long long done = 0, left = 0;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t task = fq[t];
+		if ((uint32_t)(task >> 62) != TK_ROUND2 || ((task >> 48) & 0x3fffu) != 2u) continue;
+		uint64_t a = aux[t];
+		uint32_t r = (uint32_t)task; int pivot = (int)((task >> 32) & 0xffffu);
+		int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
+		if (r2_by_text(A, r, a & ((1ull << 37) - 1ull), beg, end, pivot)) { fq[t] = FTASK_NONE; ++done; } else ++left;
+	}
+	for (int o = 32; o > 0; o >>= 1) { done += __shfl_xor(done, o); left += __shfl_xor(left, o); }
+	if ((threadIdx.x & 63u) == 0) { if (done) atomicAdd(n_done, done); if (left) atomicAdd(n_left, left); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -78,7 +78,8 @@ typedef struct {
 /* counters in the spirit of display_profile (main.cpp:203-214), accumulated over the engine's lifetime */
 typedef struct {
 	uint64_t reads, bases, mems, seeds;
-	uint64_t bwt_queries;      /* bwt_extend queries issued on the device ("BWT-extend queries")          */
+	uint64_t bwt_queries;      /* bwt_extend queries evaluated on the device ("BWT-extend queries"); equals the
+	                              reference's count unless re-seeding calls were answered from the text (below)  */
 	uint64_t bwt_calls;        /* of those, served from HBM/L2, i.e. not by the on-device SST               */
 	uint64_t sal_queries;      /* SA slots requested                                                        */
 	uint64_t sal_calls;        /* SA slots actually walked (after on-device dedup)                          */
@@ -89,6 +90,9 @@ typedef struct {
 	uint64_t seed_kernel_launches;
 	double   overflow_kernel_ms;       /* ... of the second-pass SMEM launches over overflowed reads        */
 	uint64_t overflow_kernel_launches;
+	uint64_t reseed_text_calls;        /* re-seeding calls (bwamem.c:241-249) answered from the text arrays
+	                                      instead of the FM index: same SMEMs, their bwt_extend queries never run */
+	uint64_t reseed_index_calls;       /* re-seeding calls of unique SMEMs that had to stay on the FM index       */
 } cs_stats_t;
 
 typedef struct cs_index  cs_index_t;   /* host copy of an index loaded from files */

@@ -58,9 +58,11 @@ def test_golden_seeds(eng, name, pname):
     res = eng.seed_batch(bases, off, ca.Params(**kw))
     _check_against_golden(res, z)
     st = eng.stats()
-    assert st["bwt_queries"] >= int(z["counters"][3])   # == unless reads overflowed into the second pass
-    if st["overflow_reads"] == 0:
-        assert st["bwt_queries"] == int(z["counters"][3])
+    if st["overflow_reads"] == 0:                       # (reads that overflow into the second pass are seeded twice)
+        if st["reseed_text_calls"] == 0:
+            assert st["bwt_queries"] == int(z["counters"][3])
+        else:                                           # re-seeding calls answered from the text: their extensions never run
+            assert st["bwt_queries"] < int(z["counters"][3])
     assert st["sal_queries"] == int(z["counters"][5])
 
 
@@ -170,6 +172,56 @@ def test_both_smem_kernels_match_golden(monkeypatch, mode):
     e.close(); ix.close()
 
 
+def test_text_mode_is_transparent(monkeypatch):
+    """CS_TEXT_MODE=0 keeps unique matches on the FM index; the default finishes them on the 2-bit text and the inverse
+    suffix array.  Same intervals, same seeds, same bwt_extend query count as the reference, fewer real index reads."""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    calls = {}
+    monkeypatch.setenv("CS_R2_TEXT", "0")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CS_TEXT_MODE", mode)
+        e = ca.Engine(ix, 0)
+        for name, pname in _data.golden_runs():
+            z, kw = _data.load_golden(name, pname)
+            bases, off = _data.load_reads(name)
+            e.reset_stats()
+            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+            st = e.stats()
+            assert st["bwt_queries"] == int(z["counters"][3]) or st["overflow_reads"] > 0
+        e.reset_stats()
+        bases, off = _data.load_reads("main100")
+        e.seed_batch(bases, off, ca.Params())
+        calls[mode] = e.stats()["bwt_calls"]
+        e.close()
+    ix.close()
+    assert calls["1"] < calls["0"]
+
+
+def test_reseeding_from_the_text_is_transparent(monkeypatch):
+    """CS_R2_TEXT=0 runs every re-seeding call (bwamem.c:241-249) on the FM index; the default answers those of unique
+    SMEMs from the repeat-length / LCP arrays when the text can decide them.  Same mems and seeds as the reference either
+    way; with it on, some calls must actually have been answered from the text and fewer extensions evaluated."""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    tot = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CS_R2_TEXT", mode)
+        e = ca.Engine(ix, 0)
+        e.reset_stats()
+        for name, pname in _data.golden_runs():
+            z, kw = _data.load_golden(name, pname)
+            bases, off = _data.load_reads(name)
+            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+        tot[mode] = e.stats()
+        e.close()
+    ix.close()
+    assert tot["0"]["reseed_text_calls"] == 0
+    assert tot["1"]["reseed_text_calls"] > 0
+    assert tot["1"]["bwt_queries"] < tot["0"]["bwt_queries"]
+    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
+
+
 def test_cli_dump_matches_golden(tmp_path):
     """the CompSeed-compatible command line: same flags, seed dump identical to the reference golden"""
     import subprocess
@@ -207,6 +259,7 @@ def test_device_sst_is_transparent(eng):
             res = eng.seed_batch(bases, off, ca.Params(sst_mode=mode, **kw))
             _check_against_golden(res, z)
             stats[mode] = eng.stats()
-        assert stats[0]["bwt_queries"] == stats[1]["bwt_queries"] == int(z["counters"][3])
+        assert stats[0]["bwt_queries"] == int(z["counters"][3]) and stats[0]["reseed_text_calls"] == 0
+        assert stats[1]["bwt_queries"] <= stats[0]["bwt_queries"]
         assert stats[0]["bwt_calls"] == stats[0]["bwt_queries"]
         assert stats[1]["bwt_calls"] < stats[1]["bwt_queries"]

@@ -23,17 +23,18 @@ f = glob.glob("/tmp/prof_%s/**/*kernel_trace.csv" % tag, recursive=True)[0]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))
       if any(k in r["Kernel_Name"] for k in ("fwd_kernel", "bwd_all_kernel", "bwd_wide_kernel", "init_tasks_kernel"))]
 ev.sort()
-passes, cur = [], None
+passes, cur, launches = [], None, []
 for s0, e0, name in ev:
     if "init_tasks" in name:
         if cur: passes.append(cur)
-        cur = [None, None, 0, 0.0]
+        cur = [None, None, 0, 0.0]; launches = []
         continue
     if cur is None: continue
+    launches.append([name.split("(")[0].split("::")[-1][:16], round((s0 - (cur[0] or s0)) / 1e6, 3), round((e0 - s0) / 1e6, 3)])
     cur[0] = s0 if cur[0] is None else min(cur[0], s0); cur[1] = e0 if cur[1] is None else max(cur[1], e0); cur[2] += 1; cur[3] += (e0 - s0) / 1e6
 if cur: passes.append(cur)
 out = [{"span_ms": (p[1] - p[0]) / 1e6, "launches": p[2], "summed_kernel_ms": p[3]} for p in passes if p[0] is not None]
-json.dump({"passes": out}, open(os.path.join(R, "gpurun_out", tag + "_stage_span.json"), "w"), indent=1)
+json.dump({"passes": out, "last_pass_launches_name_startms_durms": launches}, open(os.path.join(R, "gpurun_out", tag + "_stage_span.json"), "w"), indent=1)
 print(json.dumps(out))
 PY
 if [ -n "$2" ]; then
