@@ -536,7 +536,8 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.bq = e->d_bq.p;
 	A.lep = e->d_lep.p; A.lep_stride = stride;
 	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p; A.jump = e->jump_k ? e->d_jump.p : nullptr; A.jump_k = e->jump_k;
-	A.fq_cap = fq_cap; A.n_f_next = C + 1;
+	A.fq_cap = fq_cap; A.n_f_next = C + 1; A.n_btasks = C + 13; A.n_text_sweeps = C + 14;
+	{ const char *ts = getenv("CS_TEXT_SWEEP"); A.text_sweep = (!ts || atoi(ts) != 0) ? 1 : 0; }
 
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;
 	uint64_t *aux_cur = r2text ? e->d_auxA.p : nullptr, *aux_nxt = r2text ? e->d_auxB.p : nullptr;
@@ -562,6 +563,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			uint64_t cn = std::min<uint64_t>(chunk, n_f - c0);
 			A.fq = cur + c0; A.n_f = cn;
 			HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+			HIP_TRY(hipMemsetAsync(C + 13, 0, sizeof(unsigned long long), s));
 			const bool r3_only = false;
 			HIP_TRY(hipMemsetAsync(e->d_bq.p, 0xff, cn * sizeof(BTask), s)); // slots without a call stay "no class"
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
@@ -602,7 +604,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 	e->st.seed_kernel_launches++;
 	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8] - H[9]; // calls = queries not answered by the on-device SST
-	e->st.reseed_text_calls += H[11]; e->st.reseed_index_calls += H[12];
+	e->st.reseed_text_calls += H[11]; e->st.reseed_index_calls += H[12]; e->st.sweep_text_calls += H[14];
 	*n_ovf_out = H[6];
 	return CS_OK;
 }

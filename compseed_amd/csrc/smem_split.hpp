@@ -53,6 +53,9 @@ struct SplitArgs {
 	uint64_t  max_mem_intv;
 	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
 	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
+	unsigned long long *n_text_sweeps;                // backward sweeps answered from the text (fwd_kernel)
+	int32_t   text_sweep;                             // that shortcut is enabled (CS_TEXT_SWEEP, default on)
+	unsigned long long *n_btasks;                     // backward calls created by this forward launch (0: the backward kernels return at once)
 	uint64_t *aux_next;                               // side word of fq_next[slot] for re-seeding calls (r2text_kernel), or null
 	BTask    *bq;                                     // backward task of forward task t: bq[t] (no atomics: 1:1)
 	uint4    *lep; uint32_t lep_stride;               // LEP list of forward task t: lep + t*lep_stride
@@ -258,12 +261,16 @@ template <int DIR> struct BaseReader {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// the call that follows a finished round-1 call: next pivot = end of the longest forward match, ambiguous bases skipped
-__device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r, int ret)
+// the call that follows a finished round-1 call at pivot x_cur: next pivot = end of the longest forward match, ambiguous
+// bases skipped.  A round-1 task carries, in the field that holds min_intv for round 2 (round 1 always uses 1), the
+// distance to the previous pivot + 1 when the forward pass ended ON the new pivot (no ambiguous base in between): no
+// match that starts at or before the previous pivot reaches beyond the new one, which bounds the new call's sweep.
+__device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r, int ret, int x_cur)
 {
 	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
 	while (x < len && A.seq[rb + x] > 3) ++x;
-	return x < len ? ftask_pack(r, (uint32_t)x, 1, TK_ROUND1) : FTASK_NONE;
+	uint32_t d = (x == ret && ret - x_cur < 16382) ? (uint32_t)(ret - x_cur) : 0u;
+	return x < len ? ftask_pack(r, (uint32_t)x, 1u + d, TK_ROUND1) : FTASK_NONE;
 }
 
 template <int BLOCK>
@@ -271,12 +278,12 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 {
 	const DevIndex &ix = A.ix;
 	bool active = false;
-	uint64_t tslot = 0; uint32_t r = 0, kind = 0, min_intv = 1;
+	uint64_t tslot = 0; uint32_t r = 0, kind = 0, min_intv = 1, dprev = 0;
 	int len = 0, x = 0, i = 0, n = 0;
 	Intv ik = {0, 0, 0};
 	BaseReader<1> rd;
 	uint4 *lep = nullptr;
-	unsigned long long my_q = 0, my_hits = 0;
+	unsigned long long my_q = 0, my_hits = 0; uint32_t my_bt = 0, my_sw = 0;
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
 	__shared__ uint4 sst[SST_ENTRIES];
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	uint32_t tw = 0; // text mode (kind == TK_TEXT): the 16 text bases around the cursor; the cursor itself lives in ik.x1
 	const int jump_k = (use_sst && A.jump && A.jump_k <= A.min_seed_len) ? A.jump_k : 0;
 	// start a round-3 segment at x: through the jump table when the next jump_k bases are all A/C/G/T, else base by base
-	auto r3_start = [&]() {
+	auto r3_start = [&]() -> bool { // true: the jump table was used
 		if (jump_k && x + jump_k <= len) {
 			uint32_t code = 0; bool clean = true;
 			for (int q = 0; q < jump_k; ++q) { uint32_t bq = rd.at(x + q); clean = clean && bq <= 3; code = code << 2 | (bq & 3); }
@@ -300,12 +307,13 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 				uint32_t e; unpack_lep(A.jump[code], ik, e);
 				i = x + jump_k; slen = jump_k; scode = 0;
 				my_q += (unsigned)(jump_k - 1); my_hits += (unsigned)(jump_k - 1);
-				return;
+				return true;
 			}
 			rd.start(A.seq, A.off[r], x); // the reader only moves forward: rewind it to the segment start
 		}
 		scode = rd.at(x); slen = 1;
 		ik = set_intv(ix, (int)scode); i = x + 1;
+		return false;
 	};
 
 	for (;;) {
@@ -316,6 +324,8 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 			uint64_t t = A.fq[tslot];
 			kind = (uint32_t)(t >> 62);
 			r = (uint32_t)t; x = (int)((t >> 32) & 0xffffu); min_intv = (uint32_t)((t >> 48) & 0x3fffu);
+			dprev = 0;
+			if (kind == TK_ROUND1) { dprev = min_intv - 1; min_intv = 1; } // see chain_round1
 			if (kind != TK_NOP && (int64_t)r < A.n_reads) {
 				uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
 				if (x < len) {
@@ -323,7 +333,17 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					lep = A.lep + tslot * A.lep_stride; n = 0;
 					if (kind == TK_ROUND3) while (x < len && rd.at(x) > 3) ++x; // first start (bwamem.c:255-256)
 					if (x < len) {
-						if (kind == TK_ROUND3) r3_start(); else { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; }
+						if (kind == TK_ROUND3) r3_start();
+						else {
+							// A round-1 call at pivot 0 keeps no LEPs (below), so its first jump_k steps can come from the
+							// jump table too, provided the jump_k-mer occurs at all (otherwise: step by step, to find where it stops)
+							bool start = true;
+							if (x == 0 && kind == TK_ROUND1 && jump_k) {
+								start = false;
+								if (r3_start() && ik.x2 == 0) { my_q -= (unsigned)(jump_k - 1); my_hits -= (unsigned)(jump_k - 1); rd.start(A.seq, rb, x); start = true; }
+							}
+							if (start) { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; }
+						}
 						active = true;
 					}
 				}
@@ -345,7 +365,29 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					if ((tpos & 15) == 0) tw = ix.text2[tpos >> 4];        // padded: readable up to and including seq_len
 				}
 				ik.x1 = tpos;
-				if (fin) { ik.x1 = isa_direct(ix, ix.seq_len - tpos); kind = TK_ROUND1; } // rank of the reverse complement of [x, i)
+				if (fin) {
+					ik.x1 = isa_direct(ix, ix.seq_len - tpos); kind = TK_ROUND1; // rank of the reverse complement of [x, i)
+					// The sweep of this call cannot pass the previous pivot x - dprev (chain_round1), and while the unique
+					// match keeps agreeing with the text in front of it, it stays the longest survivor and nothing else is
+					// reported (bwt.c:328-336).  So if the dprev - 1 bases between the pivots agree, the whole sweep reports
+					// exactly one SMEM, [x - dprev + 1, i), and its bi-interval comes from the inverse suffix array.
+					if (dprev > 0 && A.text_sweep) {
+						const int nb = (int)dprev - 1;
+						const uint64_t px = tpos - (uint64_t)(i - x); // text position of read base x
+						bool same = px >= (uint64_t)nb;
+						const uint64_t rbase = A.off[r];
+						for (int q = 1; same && q <= nb; ++q) {
+							uint64_t tp = px - (uint64_t)q;
+							same = ((ix.text2[tp >> 4] >> ((uint32_t)(tp & 15) << 1)) & 3u) == (uint32_t)A.seq[rbase + (uint64_t)(x - q)];
+						}
+						if (same) {
+							Intv m = {isa_direct(ix, px - (uint64_t)nb), ik.x1, 1};
+							push0 = emit_smem(A, r, TK_ROUND1, m, x - nb, (uint32_t)i, aux0);
+							push1 = chain_round1(A, r, i, x);
+							++my_sw; active = false; fin = false;
+						}
+					}
+				}
 			} else {
 				// ---- the one extension site: forward by read base i (bwt.c:309-311 / 368-369)
 				uint32_t b = i < len ? rd.at(i) : 4u;
@@ -387,12 +429,13 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 				// forward match, so it needs no LEP list, no backward task, and finishes right here.
 				if (x == 0) {
 					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i, aux0);
-					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i);
+					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i, x);
 				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
 					lep[n++] = pack_lep(ik, (uint32_t)i);
 					uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
 					BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
 					A.bq[tslot] = bt;
+					++my_bt;
 				}
 				active = false;
 			}
@@ -403,6 +446,8 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+	if (my_bt) atomicAdd(A.n_btasks, (unsigned long long)my_bt);
+	if (my_sw) atomicAdd(A.n_text_sweeps, (unsigned long long)my_sw);
 }
 
 
@@ -419,7 +464,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 	const uint64_t gmask = (G >= 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << gbase);
 	bool active = false, live = false;
 	uint32_t r = 0, kind = 0, min_intv = 1, pend = 0;
-	int i = 0, ret = 0, nm = 0, last_start = 0;
+	int i = 0, ret = 0, nm = 0, last_start = 0, xp = 0;
 	Intv e = {0, 0, 0};
 	BaseReader<-1> rd;
 
@@ -459,7 +504,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 			if (mine) {
 				BTask bt = bq[t];
 				r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
-				int x = bt.x, n = bt.n;
+				int x = bt.x, n = bt.n; xp = x;
 				live = (int)gl < n;
 				if (live) unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend);
 				uint64_t rb = A.off[r];
@@ -511,7 +556,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				if (cand_m == 0) end_call = true; else --i; // the first surviving match is always kept
 			}
 			if (end_call) {
-				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(A, r, ret);
+				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(A, r, ret, xp);
 				active = false;
 			}
 		}
@@ -583,7 +628,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 			if (w == n) break;
 			lo = w;
 		}
-		uint64_t push1 = (kind == TK_ROUND1 && lane == 0) ? chain_round1(A, r, bt.ret) : FTASK_NONE;
+		uint64_t push1 = (kind == TK_ROUND1 && lane == 0) ? chain_round1(A, r, bt.ret, bt.x) : FTASK_NONE;
 		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
 	}
 }
@@ -595,6 +640,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
+	if (*A.n_btasks == 0) return; // e.g. the first launch of a batch: every call sits at pivot 0 and needs no sweep
 	WaveOut O = {0, 0};
 	unsigned long long my_q = 0, my_hits = 0;
 	__shared__ uint4 sst[SST_ENTRIES];
@@ -621,6 +667,7 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 // the calls with more than 64 LEPs, one wave each; rare, so it runs beside bwd_all_kernel on its own stream
 __global__ __launch_bounds__(256) void bwd_wide_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr)
 {
+	if (*A.n_btasks == 0) return;
 	WaveOut O = {0, 0};
 	unsigned long long my_q = 0;
 	bwd_wide_run(A, bq, n_tasks, ctr, O, my_q);
@@ -660,7 +707,7 @@ __global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n
 			if (!kept) break;
 			lo = w;
 		}
-		if (kind == TK_ROUND1) { uint64_t t2 = chain_round1(A, r, bt.ret); if (t2 != FTASK_NONE) push_ftask(A, t2); }
+		if (kind == TK_ROUND1) { uint64_t t2 = chain_round1(A, r, bt.ret, bt.x); if (t2 != FTASK_NONE) push_ftask(A, t2); }
 	}
 	atomicAdd(A.n_queries, my_q);
 }

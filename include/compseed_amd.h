@@ -93,6 +93,7 @@ typedef struct {
 	uint64_t reseed_text_calls;        /* re-seeding calls (bwamem.c:241-249) answered from the text arrays
 	                                      instead of the FM index: same SMEMs, their bwt_extend queries never run */
 	uint64_t reseed_index_calls;       /* re-seeding calls of unique SMEMs that had to stay on the FM index       */
+	uint64_t sweep_text_calls;         /* round-1 calls whose backward sweep (bwt.c:325-345) was read off the text  */
 } cs_stats_t;
 
 typedef struct cs_index  cs_index_t;   /* host copy of an index loaded from files */

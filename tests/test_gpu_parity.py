@@ -59,7 +59,7 @@ def test_golden_seeds(eng, name, pname):
     _check_against_golden(res, z)
     st = eng.stats()
     if st["overflow_reads"] == 0:                       # (reads that overflow into the second pass are seeded twice)
-        if st["reseed_text_calls"] == 0:
+        if st["reseed_text_calls"] + st["sweep_text_calls"] == 0:
             assert st["bwt_queries"] == int(z["counters"][3])
         else:                                           # re-seeding calls answered from the text: their extensions never run
             assert st["bwt_queries"] < int(z["counters"][3])
@@ -179,6 +179,7 @@ def test_text_mode_is_transparent(monkeypatch):
     ix = ca.Index.load(_data.PREFIX)
     calls = {}
     monkeypatch.setenv("CS_R2_TEXT", "0")
+    monkeypatch.setenv("CS_TEXT_SWEEP", "0")
     for mode in ("0", "1"):
         monkeypatch.setenv("CS_TEXT_MODE", mode)
         e = ca.Engine(ix, 0)
@@ -218,6 +219,29 @@ def test_reseeding_from_the_text_is_transparent(monkeypatch):
     ix.close()
     assert tot["0"]["reseed_text_calls"] == 0
     assert tot["1"]["reseed_text_calls"] > 0
+    assert tot["1"]["bwt_queries"] < tot["0"]["bwt_queries"]
+    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
+
+
+def test_sweeps_read_off_the_text_are_transparent(monkeypatch):
+    """CS_TEXT_SWEEP=0 runs every backward sweep (bwt.c:325-345) on the FM index; the default reads the sweep of a
+    round-1 call off the text when its longest match is unique and agrees with the text back to the previous pivot."""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    tot = {}
+    monkeypatch.setenv("CS_R2_TEXT", "0")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CS_TEXT_SWEEP", mode)
+        e = ca.Engine(ix, 0)
+        e.reset_stats()
+        for name, pname in _data.golden_runs():
+            z, kw = _data.load_golden(name, pname)
+            bases, off = _data.load_reads(name)
+            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+        tot[mode] = e.stats()
+        e.close()
+    ix.close()
+    assert tot["0"]["sweep_text_calls"] == 0 and tot["1"]["sweep_text_calls"] > 0
     assert tot["1"]["bwt_queries"] < tot["0"]["bwt_queries"]
     assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
 
