@@ -538,6 +538,10 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p; A.jump = e->jump_k ? e->d_jump.p : nullptr; A.jump_k = e->jump_k;
 	A.fq_cap = fq_cap; A.n_f_next = C + 1; A.n_btasks = C + 13; A.n_text_sweeps = C + 14;
 	{ const char *ts = getenv("CS_TEXT_SWEEP"); A.text_sweep = (!ts || atoi(ts) != 0) ? 1 : 0; }
+	{ // window scheme for the backward sweeps (smem_split.hpp, bwd_win_run): needs the jump table and jump_k <= min_seed_len <= jump_k + 4
+		const char *ws = getenv("CS_WINDOW");
+		A.win = (!ws || atoi(ws) != 0) && par->sst_mode != 0 && A.jump && A.jump_k <= A.min_seed_len && A.min_seed_len - 1 <= WIN_LANES ? 1 : 0;
+	}
 
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;
 	uint64_t *aux_cur = r2text ? e->d_auxA.p : nullptr, *aux_nxt = r2text ? e->d_auxB.p : nullptr;
@@ -577,8 +581,10 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 				hipLaunchKernelGGL(bwd_wide_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
 				                   (const BTask *)e->d_bq.p, cn, C + 5);
 				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
-				hipLaunchKernelGGL((bwd_all_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A,
-				                   (const BTask *)e->d_bq.p, cn, C + 2);
+				if (A.win) hipLaunchKernelGGL((bwd_win_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), dim3(256), 0, s, A,
+				                              (const BTask *)e->d_bq.p, cn, C + 2);
+				else hipLaunchKernelGGL((bwd_all_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A,
+				                        (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // both must be done before the slots and the LEP arena are reused
 			}
@@ -593,6 +599,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); return 1; }
 		n_f = H[1];
+		if (getenv("CS_VERBOSE")) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, unique finals with a known previous pivot %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[15], H[11], H[12]);
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
 		std::swap(cur, nxt); std::swap(aux_cur, aux_nxt);
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots

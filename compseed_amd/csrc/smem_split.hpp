@@ -31,6 +31,9 @@ namespace csd {
 
 enum : uint32_t { TK_ROUND1 = 0, TK_ROUND2 = 1, TK_ROUND3 = 2, TK_NOP = 3, TK_TEXT = 4 /* fwd_kernel-internal: a round-1 call in text mode */ };
 
+// window scheme (bwd_win_run): lanes 0..WIN_LANES-1 of a group hold the short matches, the rest hold LEPs
+constexpr int WIN_LANES = 18, WIN_G32_LEPS = 32 - WIN_LANES, WIN_G64_LEPS = 64 - WIN_LANES;
+
 // forward task, 8 bytes: read | pivot | min_intv | kind
 __device__ __host__ __forceinline__ uint64_t ftask_pack(uint32_t r, uint32_t x, uint32_t min_intv, uint32_t kind)
 {
@@ -54,6 +57,7 @@ struct SplitArgs {
 	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
 	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
 	unsigned long long *n_text_sweeps;                // backward sweeps answered from the text (fwd_kernel)
+	int32_t   win;                                    // window scheme for the backward sweeps (bwd_win_run) is on
 	int32_t   text_sweep;                             // that shortcut is enabled (CS_TEXT_SWEEP, default on)
 	unsigned long long *n_btasks;                     // backward calls created by this forward launch (0: the backward kernels return at once)
 	uint64_t *aux_next;                               // side word of fq_next[slot] for re-seeding calls (r2text_kernel), or null
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	Intv ik = {0, 0, 0};
 	BaseReader<1> rd;
 	uint4 *lep = nullptr;
-	unsigned long long my_q = 0, my_hits = 0; uint32_t my_bt = 0, my_sw = 0;
+	unsigned long long my_q = 0, my_hits = 0; uint32_t my_bt = 0, my_sw = 0, my_dbg = 0;
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
 	__shared__ uint4 sst[SST_ENTRIES];
@@ -371,6 +375,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					// match keeps agreeing with the text in front of it, it stays the longest survivor and nothing else is
 					// reported (bwt.c:328-336).  So if the dprev - 1 bases between the pivots agree, the whole sweep reports
 					// exactly one SMEM, [x - dprev + 1, i), and its bi-interval comes from the inverse suffix array.
+					if (dprev > 0) ++my_dbg;
 					if (dprev > 0 && A.text_sweep) {
 						const int nb = (int)dprev - 1;
 						const uint64_t px = tpos - (uint64_t)(i - x); // text position of read base x
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 				} else { // ---- forward pass of an SMEM call, bwt.c:303-320
 					const bool changed = b > 3 || y.x2 != ik.x2;            // read end (i == len), ambiguous base, or size change
 					fin = b > 3 || (y.x2 != ik.x2 && y.x2 < min_intv);
-					if (changed && !fin && x != 0) lep[n++] = pack_lep(ik, (uint32_t)i);
+					if (changed && !fin && x != 0 && (!A.win || i - x >= A.min_seed_len)) lep[n++] = pack_lep(ik, (uint32_t)i);
 					if (!fin) {
 						ik = y; ++i;
 						if (text_on && ik.x2 == 1 && kind == TK_ROUND1) { // unique from here on: continue on the text
@@ -431,8 +436,9 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i, aux0);
 					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i, x);
 				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
-					lep[n++] = pack_lep(ik, (uint32_t)i);
+					if (!A.win || i - x >= A.min_seed_len) lep[n++] = pack_lep(ik, (uint32_t)i);
 					uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
+					if (A.win) cls = n <= WIN_G32_LEPS ? 4u : n <= WIN_G64_LEPS ? 5u : 3u;
 					BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
 					A.bq[tslot] = bt;
 					++my_bt;
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
 	if (my_bt) atomicAdd(A.n_btasks, (unsigned long long)my_bt);
 	if (my_sw) atomicAdd(A.n_text_sweeps, (unsigned long long)my_sw);
+	if (my_dbg) atomicAdd(A.n_text_sweeps + 1, (unsigned long long)my_dbg);
 }
 
 
@@ -565,6 +572,133 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 	}
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The backward sweep without the triangle ("window scheme").
+//
+// bwt.c:325-345 carries every LEP of the forward pass backward in lockstep: with ~16 LEPs that die after ~16 steps that
+// is ~136 extensions per call, almost all of them spent on matches that never reach min_seed_len and are thrown away by
+// the length filter (bwamem.c:232,246).  What the sweep reports can be stated per match END t (x < t <= ret):
+//   let f(t) = the first position, going left from the pivot, at which [f, t) no longer has min_intv occurrences (or the
+//   read start / an ambiguous base); f is monotone in t (a longer end dies no later);
+//   the LEP ending at t is reported, as [f(t)+1, t), iff every longer LEP died strictly earlier, i.e. f(t) < f(t') for
+//   the nearest longer end t' (the first-survivor rule of bwt.c:328-336; LEPs dropped by the equal-size rule of
+//   bwt.c:337-340 have the same occurrences as a longer one, hence the same f, and are never reported either way).
+// Only reports of at least min_seed_len bases are kept, and a bi-interval is a function of the string alone.  So an end
+// t < x + min_seed_len matters only if the min_seed_len-mer [t - min_seed_len, t) occurs at all, and that is looked up
+// directly: the jump table gives the bi-interval of its last jump_k bases, min_seed_len - jump_k backward extensions
+// decide (a random 19-mer occurs in a 6 Gbp text with probability 2 %).  A lane that survives walks on alone to its f(t).
+// Ends that are not looked at die inside their window, i.e. later than any reported shorter end, so the rule above can
+// be evaluated over the lanes that did survive.  Ends t >= x + min_seed_len are the LEPs the forward pass stored (it
+// stores no others under this scheme); each walks alone from the pivot.  ~16 table reads + ~40 extensions, 5 deep,
+// replace 136 extensions, 17 deep; results identical.
+//
+// A group of G lanes per call: lanes 0..17 take the ends x+1 .. x+18, lanes 18.. take the stored LEPs in ascending order.
+__device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, uint64_t rb, int x, int ret, uint32_t min_intv,
+                                              Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits)
+{
+	const int k = A.min_seed_len, jk = A.jump_k;
+	const int te = x + 1 + (int)gl;
+	if ((int)gl >= k - 1 || te > ret || te - k < 0) return false;
+	// the jump_k bases [te - jk, te) out of three aligned 8-byte words of the read
+	const uint64_t a = rb + (uint64_t)(te - jk), a0 = a & ~7ull;
+	const uint64_t *w = reinterpret_cast<const uint64_t *>(A.seq + a0);
+	uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+	uint32_t code = 0, bad = 0;
+	for (int q = 0; q < jk; ++q) {
+		uint32_t o = (uint32_t)(a - a0) + (uint32_t)q;
+		uint64_t word = o < 8 ? w0 : o < 16 ? w1 : w2;
+		uint32_t b = (uint32_t)(word >> ((o & 7u) << 3)) & 0xffu;
+		bad |= b; code = code << 2 | (b & 3u);
+	}
+	if (bad > 3) return false; // an ambiguous base inside the window: this end cannot reach min_seed_len
+	uint32_t dummy; unpack_lep(A.jump[code], e, dummy);
+	my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
+	if (e.x2 < min_intv) return false;
+	pend = (uint32_t)te; s = te - jk - 1;
+	return true;
+}
+
+template <int G>
+__device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
+                                            unsigned long long &my_q, unsigned long long &my_hits)
+{
+	constexpr uint32_t MYCLS = G == 32 ? 4u : 5u;
+	const DevIndex &ix = A.ix;
+	const uint32_t lane = threadIdx.x & 63u, gl = lane % G, gbase = lane - gl;
+	const uint64_t gmask = (G >= 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << gbase);
+	bool active = false, walking = false, valid = false;
+	uint32_t r = 0, kind = 0, min_intv = 1, pend = 0;
+	int s = 0, f = 0, ret = 0, xp = 0;
+	Intv e = {0, 0, 0};
+	BaseReader<-1> rd;
+	uint64_t batch_base = 0, avail_m = 0; bool exhausted = false;
+	for (;;) { // task acquisition exactly as in bwd_groups_run
+		uint64_t idle_m = __ballot(!active && gl == 0);
+		if (idle_m != 0 && avail_m == 0 && !exhausted) {
+			int src = __ffsll((long long)idle_m) - 1;
+			unsigned long long base = 0;
+			if ((int)lane == src) base = atomicAdd(ctr, 64ull);
+			base = __shfl(base, src);
+			if (base >= n_tasks) exhausted = true;
+			else {
+				uint64_t slot = base + lane;
+				uint32_t cls = slot < n_tasks ? bq[slot].cls : 0xffffffffu;
+				avail_m = __ballot(cls == MYCLS);
+				batch_base = base;
+			}
+		}
+		if (idle_m != 0 && avail_m != 0) {
+			int kth = __popcll(idle_m & ((1ull << gbase) - 1ull));
+			uint64_t m = avail_m;
+			for (int q = 0; q < kth; ++q) m &= m - 1;
+			bool mine = !active && m != 0;
+			uint64_t t = batch_base + (uint64_t)(__ffsll((long long)m) - 1);
+			int taken = __popcll(idle_m), have = __popcll(avail_m);
+			if (taken > have) taken = have;
+			for (int q = 0; q < taken; ++q) avail_m &= avail_m - 1;
+			if (mine) {
+				BTask bt = bq[t];
+				r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret; xp = bt.x;
+				const int n = bt.n;
+				const uint64_t rb = A.off[r];
+				f = 0x7fffffff;
+				if (gl < (uint32_t)WIN_LANES) valid = win_lane_init(A, gl, rb, xp, ret, min_intv, e, pend, s, my_q, my_hits);
+				else {
+					int j = (int)gl - WIN_LANES;
+					valid = j < n;
+					if (valid) { unpack_lep(A.lep[(size_t)t * A.lep_stride + j], e, pend); s = xp - 1; }
+				}
+				walking = valid;
+				if (valid) rd.start(A.seq, rb, s);
+				active = true;
+			}
+		}
+		if (exhausted && avail_m == 0 && __ballot(active) == 0) break; // wave-uniform exit
+		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
+		if (active) {
+			if (walking) { // every lane walks alone: backward by read base s until the match has fewer than min_intv occurrences
+				uint32_t b = s < 0 ? 4u : rd.at(s);
+				if (b > 3) { f = s; walking = false; }
+				else {
+					Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
+				}
+			}
+			if ((__ballot(walking) & gmask) == 0) { // all ends of this call are settled: apply the first-survivor rule
+				uint64_t vm = __ballot(valid) & gmask;
+				uint64_t higher = lane == 63 ? 0ull : vm & ~((2ull << lane) - 1ull);
+				int src = higher ? __ffsll((long long)higher) - 1 : (int)lane;
+				int fn = __shfl(f, src);
+				if (valid && (higher == 0 || f < fn)) push0 = emit_smem(A, r, kind, e, f + 1, pend, aux0);
+				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(A, r, ret, xp);
+				active = false; valid = false;
+			}
+		}
+		wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
+		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
+	}
+}
+
 // Calls with more than 64 LEPs (tandem arrays, very long reads): one WAVE per call, the list stays in HBM and every step
 // of the sweep streams the live part through the wave 64 entries at a time, longest first, compacting it in place (the
 // write index never passes below the chunk being processed).  Same rules as above; the "previous surviving size" is
@@ -594,7 +728,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 		uint32_t r = bt.r, kind = bt.mi_kind >> 14, min_intv = bt.mi_kind & 0x3fffu;
 		uint4 *lep = A.lep + (size_t)t * A.lep_stride;
 		uint64_t rb = A.off[r];
-		int n = bt.n, lo = 0, nm = 0, last_start = 0;
+		int n = bt.n, lo = 0, nm = 0, last_start = 0, f_long = 0x7fffffff;
 		for (int i = (int)bt.x - 1; i >= -1; --i) {
 			uint32_t b = i < 0 ? 4u : A.seq[rb + i];
 			int w = n; bool first_done = false, have_prev = false; uint64_t prev_carry = 0, push0 = FTASK_NONE, aux0 = AUX_NONE;
@@ -625,8 +759,34 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 			}
 			__threadfence_block(); // the compacted list is read back by other lanes of this wave in the next step
 			wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
+			f_long = i;            // the step at which the last stored LEP died, if this is the last step
 			if (w == n) break;
 			lo = w;
+		}
+		if (A.win) { // window scheme: the forward pass stored only the LEPs of min_seed_len bases or more; the short ends are
+			// settled here by lanes 0..17 (bwd_win_run), the nearest longer end of the longest of them being the list above
+			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0, f = 0x7fffffff;
+			unsigned long long hits = 0;
+			bool valid = lane < (uint32_t)WIN_LANES && win_lane_init(A, lane, rb, (int)bt.x, (int)bt.ret, min_intv, e, pend, s, my_q, hits);
+			bool walking = valid;
+			while (__ballot(walking)) {
+				if (walking) {
+					uint32_t b = s < 0 ? 4u : A.seq[rb + (uint64_t)s];
+					if (b > 3) { f = s; walking = false; }
+					else {
+						Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+						if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
+					}
+				}
+			}
+			uint64_t vm = __ballot(valid);
+			uint64_t higher = vm & ~((2ull << lane) - 1ull);
+			int src = higher ? __ffsll((long long)higher) - 1 : (int)lane;
+			int fn = __shfl(f, src);
+			if (!higher) fn = f_long;
+			uint64_t pushw = FTASK_NONE, auxw = AUX_NONE;
+			if (valid && f < fn) pushw = emit_smem(A, r, kind, e, f + 1, pend, auxw);
+			wave_push<32>(O, pushw != FTASK_NONE, pushw, A, auxw);
 		}
 		uint64_t push1 = (kind == TK_ROUND1 && lane == 0) ? chain_round1(A, r, bt.ret, bt.x) : FTASK_NONE;
 		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
@@ -658,6 +818,25 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
 		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
 		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
+	}
+	wave_push_finish(O, A);
+	atomicAdd(A.n_queries, my_q);
+	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+}
+
+// window scheme: ctrs[0] / ctrs[1] are the slot counters of the classes with up to 14 / 46 stored LEPs
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 5) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
+{
+	if (*A.n_btasks == 0) return;
+	WaveOut O = {0, 0};
+	unsigned long long my_q = 0, my_hits = 0;
+	if ((blockIdx.x & 7u) != 7u) {
+		bwd_win_run<32>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits);
+		bwd_win_run<64>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits);
+	} else {
+		bwd_win_run<64>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits);
+		bwd_win_run<32>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits);
 	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
