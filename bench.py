@@ -161,6 +161,7 @@ def main():
                            "device_sst_hit_rate": 1.0 - st["bwt_calls"] / max(1, st["bwt_queries"]),
                            "reference_sst_hit_rate": 1.0 - ws["bwt_calls"] / max(1, ws["bwt_queries"]),
                            "reference_bwt_extend_queries_per_read": ws["bwt_queries"] / nchk,
+                           "round3_seeds_from_text_per_read": st["r3_text_seeds"] / (args.reads * args.steps),
                            "sweeps_read_off_the_text_per_read": st["sweep_text_calls"] / (args.reads * args.steps),
                            "reseed_calls_answered_from_text_per_read": st["reseed_text_calls"] / (args.reads * args.steps),
                            "reseed_calls_of_unique_smems_left_to_index_per_read": st["reseed_index_calls"] / (args.reads * args.steps),

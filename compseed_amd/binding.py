@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("sal_calls", C.c_uint64), ("overflow_reads", C.c_uint64), ("seed_kernel_ms", C.c_double),
                 ("sal_kernel_ms", C.c_double), ("total_ms", C.c_double), ("seed_kernel_launches", C.c_uint64),
                 ("overflow_kernel_ms", C.c_double), ("overflow_kernel_launches", C.c_uint64),
-                ("reseed_text_calls", C.c_uint64), ("reseed_index_calls", C.c_uint64), ("sweep_text_calls", C.c_uint64)]
+                ("reseed_text_calls", C.c_uint64), ("reseed_index_calls", C.c_uint64), ("sweep_text_calls", C.c_uint64),
+                ("r3_text_seeds", C.c_uint64)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -549,8 +549,11 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	HIP_TRY(hipEventRecord(e->ev[0], s));
 	hipLaunchKernelGGL(init_tasks_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, A, cur, e->d_fqR.p);
 	// Round 3 depends on nothing: it runs on a low-priority second stream and fills the tails of the launches below.
-	bool r3_async = A.max_mem_intv > 0;
-	if (r3_async) {
+	const int r3_text_env = getenv("CS_R3_TEXT") ? atoi(getenv("CS_R3_TEXT")) : 1;
+	const bool r3_text = A.max_mem_intv > 0 && r2text && r3_text_env != 0; // round 3 after rounds 1/2, mostly from the text (r3text_kernel)
+	bool r3_async = A.max_mem_intv > 0 && !r3_text;
+	const int r3_after = getenv("CS_R3_AFTER") ? atoi(getenv("CS_R3_AFTER")) : 0; // start round 3 after this many forward launches
+	auto launch_r3 = [&]() -> int {
 		SplitArgs R = A;
 		R.fq = e->d_fqR.p; R.n_f = (uint64_t)nb; R.task_ctr = C + 10;
 		HIP_TRY(hipEventRecord(e->ev_r3a, s));
@@ -559,7 +562,10 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		hipLaunchKernelGGL((fwd_kernel<256>), dim3(gr), dim3(256), 0, e->stream2, R);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
-	}
+		return CS_OK;
+	};
+	bool r3_launched = false;
+	if (r3_async && r3_after <= 0) { CS_TRY(launch_r3()); r3_launched = true; }
 	uint64_t n_f = (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
 		A.fq_next = nxt; A.aux_next = aux_nxt;
@@ -573,6 +579,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
 			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
 			HIP_TRY(hipGetLastError());
+			if (r3_async && !r3_launched && iter + 1 >= r3_after) { CS_TRY(launch_r3()); r3_launched = true; }
 			if (!r3_only) { // one launch works through all four size classes of the chunk's backward sweeps
 				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
@@ -580,6 +587,8 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
 				hipLaunchKernelGGL(bwd_wide_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
 				                   (const BTask *)e->d_bq.p, cn, C + 5);
+				if (A.win) hipLaunchKernelGGL((bwd_win0_kernel<256>), dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 8, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				                              (const BTask *)e->d_bq.p, cn); // the calls without stored LEPs, beside the others
 				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
 				if (A.win) hipLaunchKernelGGL((bwd_win_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), dim3(256), 0, s, A,
 				                              (const BTask *)e->d_bq.p, cn, C + 2);
@@ -599,11 +608,16 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); return 1; }
 		n_f = H[1];
-		if (getenv("CS_VERBOSE")) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, unique finals with a known previous pivot %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[15], H[11], H[12]);
+		if (getenv("CS_VERBOSE")) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[11], H[12]);
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
 		std::swap(cur, nxt); std::swap(aux_cur, aux_nxt);
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
+	if (r3_text) {
+		hipLaunchKernelGGL(r3text_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 16, ((uint64_t)nb + 255) / 256)), dim3(256), 0, s, A, C + 15);
+		HIP_TRY(hipGetLastError());
+	}
+	if (r3_async && !r3_launched) { CS_TRY(launch_r3()); r3_launched = true; }
 	if (r3_async) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
 	HIP_TRY(hipEventRecord(e->ev[1], s));
 	HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -611,7 +625,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 	e->st.seed_kernel_launches++;
 	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8] - H[9]; // calls = queries not answered by the on-device SST
-	e->st.reseed_text_calls += H[11]; e->st.reseed_index_calls += H[12]; e->st.sweep_text_calls += H[14];
+	e->st.reseed_text_calls += H[11]; e->st.reseed_index_calls += H[12]; e->st.sweep_text_calls += H[14]; e->st.r3_text_seeds += H[15];
 	*n_ovf_out = H[6];
 	return CS_OK;
 }

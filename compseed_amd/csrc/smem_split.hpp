@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	Intv ik = {0, 0, 0};
 	BaseReader<1> rd;
 	uint4 *lep = nullptr;
-	unsigned long long my_q = 0, my_hits = 0; uint32_t my_bt = 0, my_sw = 0, my_dbg = 0;
+	unsigned long long my_q = 0, my_hits = 0; uint32_t my_bt = 0, my_sw = 0;
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
 	__shared__ uint4 sst[SST_ENTRIES];
@@ -341,10 +341,11 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 						else {
 							// A round-1 call at pivot 0 keeps no LEPs (below), so its first jump_k steps can come from the
 							// jump table too, provided the jump_k-mer occurs at all (otherwise: step by step, to find where it stops)
+							// (the same holds for every call under the window scheme: LEPs shorter than min_seed_len are not stored)
 							bool start = true;
-							if (x == 0 && kind == TK_ROUND1 && jump_k) {
+							if (((x == 0 && kind == TK_ROUND1) || A.win) && jump_k) {
 								start = false;
-								if (r3_start() && ik.x2 == 0) { my_q -= (unsigned)(jump_k - 1); my_hits -= (unsigned)(jump_k - 1); rd.start(A.seq, rb, x); start = true; }
+								if (r3_start() && ik.x2 < min_intv) { my_q -= (unsigned)(jump_k - 1); my_hits -= (unsigned)(jump_k - 1); rd.start(A.seq, rb, x); start = true; }
 							}
 							if (start) { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; }
 						}
@@ -375,7 +376,6 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					// match keeps agreeing with the text in front of it, it stays the longest survivor and nothing else is
 					// reported (bwt.c:328-336).  So if the dprev - 1 bases between the pivots agree, the whole sweep reports
 					// exactly one SMEM, [x - dprev + 1, i), and its bi-interval comes from the inverse suffix array.
-					if (dprev > 0) ++my_dbg;
 					if (dprev > 0 && A.text_sweep) {
 						const int nb = (int)dprev - 1;
 						const uint64_t px = tpos - (uint64_t)(i - x); // text position of read base x
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
 					if (!A.win || i - x >= A.min_seed_len) lep[n++] = pack_lep(ik, (uint32_t)i);
 					uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
-					if (A.win) cls = n <= WIN_G32_LEPS ? 4u : n <= WIN_G64_LEPS ? 5u : 3u;
+					if (A.win) cls = n == 0 ? 6u : n <= WIN_G32_LEPS ? 4u : n <= WIN_G64_LEPS ? 5u : 3u;
 					BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
 					A.bq[tslot] = bt;
 					++my_bt;
@@ -454,7 +454,6 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
 	if (my_bt) atomicAdd(A.n_btasks, (unsigned long long)my_bt);
 	if (my_sw) atomicAdd(A.n_text_sweeps, (unsigned long long)my_sw);
-	if (my_dbg) atomicAdd(A.n_text_sweeps + 1, (unsigned long long)my_dbg);
 }
 
 
@@ -824,6 +823,71 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
 }
 
+// Calls without any stored LEP (the forward match is shorter than min_seed_len: typically the call at a mismatch, whose
+// matches are all chance matches) are the bulk, and all their work is the 18 window lookups, of which 98 % die within
+// four extensions.  They get a kernel of their own that packs three calls into a wave (54 of 64 lanes busy) instead of
+// one call per 32-lane group: a wave owns 64 consecutive slots, finds this class by ballot and works through it three
+// at a time.  Nothing is carried between rounds, so no dispenser and no atomics on the task side.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void bwd_win0_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
+{
+	if (*A.n_btasks == 0) return;
+	__shared__ uint8_t rank2lane[BLOCK / 64][64];
+	const DevIndex &ix = A.ix;
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	const uint32_t seg = lane / WIN_LANES, gl = lane - seg * WIN_LANES;      // three segments of 18 lanes; lanes 54..63 idle
+	const uint64_t segmask = seg < 3 ? ((1ull << WIN_LANES) - 1ull) << (seg * WIN_LANES) : 0ull;
+	WaveOut O = {0, 0};
+	unsigned long long my_q = 0, my_hits = 0;
+	const uint64_t n_batches = (n_tasks + 63) / 64, wstride = (uint64_t)gridDim.x * (BLOCK / 64);
+	for (uint64_t bch = (uint64_t)blockIdx.x * (BLOCK / 64) + wv; bch < n_batches; bch += wstride) { // wave-uniform
+		const uint64_t slot = bch * 64 + lane;
+		BTask bt = {0, 0, 0, 0, 0, 0xffffffffu};
+		if (slot < n_tasks) bt = bq[slot];
+		const bool is = bt.cls == 6u;
+		const uint64_t m = __ballot(is);
+		const int cnt = __popcll(m);
+		if (cnt == 0) continue;
+		if (is) rank2lane[wv][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+		__builtin_amdgcn_wave_barrier();
+		for (int r0 = 0; r0 < cnt; r0 += 3) { // wave-uniform
+			const int rank = r0 + (int)seg;
+			const bool job = seg < 3 && rank < cnt;
+			const int src = job ? (int)rank2lane[wv][rank] : (int)lane;
+			const uint32_t r = __shfl(bt.r, src), mk = __shfl((uint32_t)bt.mi_kind, src);
+			const int x = __shfl((int)bt.x, src), ret = __shfl((int)bt.ret, src);
+			const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
+			const uint64_t rb = job ? A.off[r] : 0;
+			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0, f = 0x7fffffff;
+			const bool valid = job && win_lane_init(A, gl, rb, x, ret, min_intv, e, pend, s, my_q, my_hits);
+			bool walking = valid;
+			while (__ballot(walking)) {
+				if (walking) {
+					uint32_t b = s < 0 ? 4u : (uint32_t)A.seq[rb + (uint64_t)s];
+					if (b > 3) { f = s; walking = false; }
+					else {
+						Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+						if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
+					}
+				}
+			}
+			const uint64_t vm = __ballot(valid) & segmask;
+			const uint64_t higher = lane == 63 ? 0ull : vm & ~((2ull << lane) - 1ull);
+			const int hsrc = higher ? __ffsll((long long)higher) - 1 : (int)lane;
+			const int fn = __shfl(f, hsrc);
+			uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
+			if (valid && (higher == 0 || f < fn)) push0 = emit_smem(A, r, kind, e, f + 1, pend, aux0);
+			if (job && gl == 0 && kind == TK_ROUND1) push1 = chain_round1(A, r, ret, x);
+			wave_push<64>(O, push0 != FTASK_NONE, push0, A, aux0);
+			wave_push<64>(O, push1 != FTASK_NONE, push1, A);
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	wave_push_finish(O, A);
+	atomicAdd(A.n_queries, my_q);
+	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+}
+
 // window scheme: ctrs[0] / ctrs[1] are the slot counters of the classes with up to 14 / 46 stored LEPs
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 5) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
@@ -974,6 +1038,73 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, uint64_t
 	}
 	for (int o = 32; o > 0; o >>= 1) { done += __shfl_xor(done, o); left += __shfl_xor(left, o); }
 	if ((threadIdx.x & 63u) == 0) { if (done) atomicAdd(n_done, done); if (left) atomicAdd(n_left, left); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3 (bwt_seed_strategy1, bwt.c:357-381; the loop of bwamem.c:253-262) after rounds 1 and 2, one lane per read.
+//
+// A round-3 seed starting at x is the shortest prefix [x, x+L), L >= min_seed_len + 1, with fewer than max_mem_intv
+// occurrences.  Where the read lies inside one of its own unique round-1 SMEMs [beg, end) -- text position P = SA[x0] --
+// the read IS the text, and for L = min_seed_len + 1 the answer is in the text arrays: rep[p] < L means the L-mer at p is
+// unique (bi-interval = two inverse-suffix-array reads), otherwise a short walk over lcp[] counts its occurrences.  Only
+// where that does not apply (the seed would leave the SMEM, 20 or more occurrences, repeats without a unique SMEM) the
+// seed is computed on the FM index as before (jump table + extensions).  Same seeds, a fraction of the index reads:
+// on the bench workload round 3 was the largest single consumer of HBM traffic.
+__global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, unsigned long long *n_text_seeds)
+{
+	const DevIndex &ix = A.ix;
+	const int k1 = A.min_seed_len + 1;
+	const int jk = (A.jump && A.jump_k <= A.min_seed_len) ? A.jump_k : 0;
+	unsigned long long my_q = 0, my_hits = 0, my_text = 0;
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+		const uint64_t rb = A.off[r]; const int len = (int)(A.off[r + 1] - rb);
+		const uint32_t nm0 = A.out_cnt[r] < A.cap ? A.out_cnt[r] : A.cap; // the mems of rounds 1 and 2 (this lane appends its own behind them)
+		const OutMem *mine = A.out + (size_t)r * A.cap;
+		int cb = 0, ce = 0; uint64_t cp = 0; // the unique SMEM the cursor is in: [cb, ce) at text position cp
+		int x = 0;
+		while (x < len) {
+			if (A.seq[rb + (uint64_t)x] > 3) { ++x; continue; }
+			if (!(x >= cb && x + k1 <= ce)) { // look for a unique SMEM that covers [x, x + k1)
+				cb = ce = 0;
+				for (uint32_t a = 0; a < nm0; ++a) {
+					const uint64_t info = mine[a].info; const int mb = (int)(info >> 32), me = (int)(uint32_t)info;
+					if (mine[a].x2 == 1 && x >= mb && x + k1 <= me) { cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0); break; }
+				}
+			}
+			if (x >= cb && x + k1 <= ce && ix.rep) {
+				const uint64_t p = cp + (uint64_t)(x - cb);
+				const uint32_t v = ix.rep[p];
+				Intv iv = {0, 0, 0}; bool ok = false;
+				if (v < (uint32_t)k1) { iv.x0 = isa_direct(ix, p); iv.x1 = isa_direct(ix, ix.seq_len - (p + (uint64_t)k1)); iv.x2 = 1; ok = true; }
+				else if (v < 255u && k1 < 255) ok = text_interval(ix, p, (uint32_t)k1, iv) && iv.x2 < A.max_mem_intv;
+				if (ok) {
+					emit_mem(A, (uint32_t)r, iv, (uint32_t)x, (uint32_t)(x + k1));
+					my_q += (unsigned)(k1 - 1); my_hits += (unsigned)(k1 - 1); ++my_text;
+					x += k1;
+					continue;
+				}
+			}
+			// bwt_seed_strategy1 on the index
+			Intv ik; int i; bool jumped = false;
+			if (jk && x + jk <= len) {
+				uint32_t code = 0, bad = 0;
+				for (int q = 0; q < jk; ++q) { uint32_t b = A.seq[rb + (uint64_t)(x + q)]; bad |= b; code = code << 2 | (b & 3u); }
+				if (bad <= 3) { uint32_t dummy; unpack_lep(A.jump[code], ik, dummy); i = x + jk; jumped = true; my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1); }
+			}
+			if (!jumped) { ik = set_intv(ix, (int)A.seq[rb + (uint64_t)x]); i = x + 1; }
+			int nx = len;
+			for (; i < len; ++i) {
+				const uint32_t b = A.seq[rb + (uint64_t)i];
+				if (b > 3) { nx = i + 1; break; }
+				const Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
+				if (y.x2 < A.max_mem_intv && i - x >= A.min_seed_len) { if (y.x2 > 0) emit_mem(A, (uint32_t)r, y, (uint32_t)x, (uint32_t)(i + 1)); nx = i + 1; break; }
+				ik = y;
+			}
+			x = nx;
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) { my_q += __shfl_xor(my_q, o); my_hits += __shfl_xor(my_hits, o); my_text += __shfl_xor(my_text, o); }
+	if ((threadIdx.x & 63u) == 0) { atomicAdd(A.n_queries, my_q); if (my_hits) atomicAdd(A.n_sst_hits, my_hits); if (my_text) atomicAdd(n_text_seeds, my_text); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -94,6 +94,7 @@ typedef struct {
 	                                      instead of the FM index: same SMEMs, their bwt_extend queries never run */
 	uint64_t reseed_index_calls;       /* re-seeding calls of unique SMEMs that had to stay on the FM index       */
 	uint64_t sweep_text_calls;         /* round-1 calls whose backward sweep (bwt.c:325-345) was read off the text  */
+	uint64_t r3_text_seeds;            /* round-3 seeds (bwt.c:357-381) whose bi-interval came from the text arrays  */
 } cs_stats_t;
 
 typedef struct cs_index  cs_index_t;   /* host copy of an index loaded from files */

@@ -272,6 +272,28 @@ def test_window_scheme_is_transparent(monkeypatch):
     assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
 
 
+def test_round3_from_the_text_is_transparent(monkeypatch):
+    """CS_R3_TEXT=0 computes every round-3 seed (bwt.c:357-381) on the FM index, beside rounds 1/2; the default runs
+    round 3 afterwards and takes the seeds that lie inside a unique round-1 SMEM from the text arrays."""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    tot = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CS_R3_TEXT", mode)
+        e = ca.Engine(ix, 0)
+        e.reset_stats()
+        for name, pname in _data.golden_runs():
+            z, kw = _data.load_golden(name, pname)
+            bases, off = _data.load_reads(name)
+            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+        tot[mode] = e.stats()
+        e.close()
+    ix.close()
+    assert tot["0"]["r3_text_seeds"] == 0 and tot["1"]["r3_text_seeds"] > 0
+    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
+    assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
+
+
 def test_cli_dump_matches_golden(tmp_path):
     """the CompSeed-compatible command line: same flags, seed dump identical to the reference golden"""
     import subprocess
