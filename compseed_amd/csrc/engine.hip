@@ -84,8 +84,8 @@ template <typename T> struct PinBuf {
 struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
-	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; // stream2: the independent round-3 chains; stream3: wide sweeps
-	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; // stream2: the independent round-3 chains; stream3: wide sweeps
+	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr, ev_wc = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
@@ -205,6 +205,8 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		HIP_TRY(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_wa, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_wb, hipEventDisableTiming));
+		HIP_TRY(hipStreamCreateWithFlags(&e->stream4, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_wc, hipEventDisableTiming));
 	}
 
 	if (v->seq_len == 0 || v->seq_len != v->L2[4] || v->L2[0] != 0) return fail(CS_EINVAL, "index view: L2 / seq_len inconsistent");
@@ -382,6 +384,8 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (e->ev_wa) (void)hipEventDestroy(e->ev_wa);
 	if (e->ev_wb) (void)hipEventDestroy(e->ev_wb);
 	if (e->stream3) (void)hipStreamDestroy(e->stream3);
+	if (e->ev_wc) (void)hipEventDestroy(e->ev_wc);
+	if (e->stream4) (void)hipStreamDestroy(e->stream4);
 	if (e->stream2) (void)hipStreamDestroy(e->stream2);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
@@ -587,15 +591,20 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
 				hipLaunchKernelGGL(bwd_wide_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
 				                   (const BTask *)e->d_bq.p, cn, C + 5);
-				if (A.win) hipLaunchKernelGGL((bwd_win0_kernel<256>), dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 8, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
-				                              (const BTask *)e->d_bq.p, cn); // the calls without stored LEPs, beside the others
 				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
+				if (A.win) { // the calls without stored LEPs, beside the others on a stream of their own
+					HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
+					hipLaunchKernelGGL((bwd_win0_kernel<256>), dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 8, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
+					                   (const BTask *)e->d_bq.p, cn);
+					HIP_TRY(hipEventRecord(e->ev_wc, e->stream4));
+				}
 				if (A.win) hipLaunchKernelGGL((bwd_win_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), dim3(256), 0, s, A,
 				                              (const BTask *)e->d_bq.p, cn, C + 2);
 				else hipLaunchKernelGGL((bwd_all_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A,
 				                        (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
-				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // both must be done before the slots and the LEP arena are reused
+				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // all must be done before the slots and the LEP arena are reused
+				if (A.win) HIP_TRY(hipStreamWaitEvent(s, e->ev_wc, 0));
 			}
 			c0 += cn;
 		}
@@ -606,7 +615,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		}
 		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
-		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); return 1; }
+		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4); return 1; }
 		n_f = H[1];
 		if (getenv("CS_VERBOSE")) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[11], H[12]);
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));

@@ -683,6 +683,16 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
 				}
 			}
+			{ // The stored LEPs all start at the pivot and step together, so the equal-size rule of bwt.c:337-340 applies to
+			  // them as it stands: a LEP with as many occurrences as the next longer surviving one has the same occurrences,
+			  // shares its fate from here on and is never reported -- it stops walking.  (In repeats this is most of them.)
+				const bool lepw = walking && gl >= (uint32_t)WIN_LANES;
+				const uint64_t lm = __ballot(lepw) & gmask;
+				const uint64_t above = lane == 63 ? 0ull : lm & ~((2ull << lane) - 1ull);
+				const int asrc = above ? __ffsll((long long)above) - 1 : (int)lane;
+				const uint64_t ax2 = __shfl(e.x2, asrc);
+				if (lepw && above && ax2 == e.x2) { walking = false; valid = false; }
+			}
 			if ((__ballot(walking) & gmask) == 0) { // all ends of this call are settled: apply the first-survivor rule
 				uint64_t vm = __ballot(valid) & gmask;
 				uint64_t higher = lane == 63 ? 0ull : vm & ~((2ull << lane) - 1ull);
