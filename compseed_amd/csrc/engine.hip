@@ -586,6 +586,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			if (r3_async && !r3_launched && iter + 1 >= r3_after) { CS_TRY(launch_r3()); r3_launched = true; }
 			if (!r3_only) { // one launch works through all four size classes of the chunk's backward sweeps
 				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
+				const int win0_occ = 8; // (sharing the CUs between the two window kernels by grid size was measured: slower in every split)
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
 				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
@@ -594,7 +595,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
 				if (A.win) { // the calls without stored LEPs, beside the others on a stream of their own
 					HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
-					hipLaunchKernelGGL((bwd_win0_kernel<256>), dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 8, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
+					hipLaunchKernelGGL((bwd_win0_kernel<256>), dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
 					                   (const BTask *)e->d_bq.p, cn);
 					HIP_TRY(hipEventRecord(e->ev_wc, e->stream4));
 				}

@@ -627,7 +627,7 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 	const uint64_t gmask = (G >= 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << gbase);
 	bool active = false, walking = false, valid = false;
 	uint32_t r = 0, kind = 0, min_intv = 1, pend = 0;
-	int s = 0, f = 0, ret = 0, xp = 0;
+	int s = 0, f = 0, ret = 0, xp = 0, clk = 0;
 	Intv e = {0, 0, 0};
 	BaseReader<-1> rd;
 	uint64_t batch_base = 0, avail_m = 0; bool exhausted = false;
@@ -669,13 +669,21 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 				}
 				walking = valid;
 				if (valid) rd.start(A.seq, rb, s);
+				clk = xp + WIN_LANES - A.jump_k - 1; // the base in front of the last window lane, the first to join
+				if (clk < xp - 1) clk = xp - 1;        // (the LEP lanes join at the pivot)
 				active = true;
 			}
 		}
 		if (exhausted && avail_m == 0 && __ballot(active) == 0) break; // wave-uniform exit
 		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
 		if (active) {
-			if (walking) { // every lane walks alone: backward by read base s until the match has fewer than min_intv occurrences
+			// One clock per group: position clk is the read base every walking lane prepends in this iteration.  A lane joins
+			// when the clock reaches the base in front of its match (the window lanes start staggered, the LEPs at the pivot),
+			// so all lanes that walk hold matches with the SAME start, and the equal-size rule of bwt.c:337-340 applies to
+			// them as it stands: a match with as many occurrences as the next longer walking one has the same occurrences,
+			// shares its fate from here on and is never reported -- it stops.  In repeats that is most lanes.
+			const bool step = walking && s == clk;
+			if (step) {
 				uint32_t b = s < 0 ? 4u : rd.at(s);
 				if (b > 3) { f = s; walking = false; }
 				else {
@@ -683,16 +691,15 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
 				}
 			}
-			{ // The stored LEPs all start at the pivot and step together, so the equal-size rule of bwt.c:337-340 applies to
-			  // them as it stands: a LEP with as many occurrences as the next longer surviving one has the same occurrences,
-			  // shares its fate from here on and is never reported -- it stops walking.  (In repeats this is most of them.)
-				const bool lepw = walking && gl >= (uint32_t)WIN_LANES;
-				const uint64_t lm = __ballot(lepw) & gmask;
+			{
+				const bool surv = step && walking;
+				const uint64_t lm = __ballot(surv) & gmask;
 				const uint64_t above = lane == 63 ? 0ull : lm & ~((2ull << lane) - 1ull);
 				const int asrc = above ? __ffsll((long long)above) - 1 : (int)lane;
 				const uint64_t ax2 = __shfl(e.x2, asrc);
-				if (lepw && above && ax2 == e.x2) { walking = false; valid = false; }
+				if (surv && above && ax2 == e.x2) { walking = false; valid = false; }
 			}
+			--clk;
 			if ((__ballot(walking) & gmask) == 0) { // all ends of this call are settled: apply the first-survivor rule
 				uint64_t vm = __ballot(valid) & gmask;
 				uint64_t higher = lane == 63 ? 0ull : vm & ~((2ull << lane) - 1ull);
