@@ -424,11 +424,10 @@ static int scan_u64(cs_engine *e, const uint64_t *cnt, uint64_t *off, size_t n)
 
 __global__ void max_len_kernel(const uint64_t *off, int64_t n, unsigned long long *out_max, unsigned long long *bad)
 {
-	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long len = 0;
-	if (r < n) {
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) { // few waves: few atomics
 		uint64_t a = off[r], b = off[r + 1];
-		if (b < a) atomicAdd(bad, 1ull); else len = b - a;
+		if (b < a) atomicAdd(bad, 1ull); else if (b - a > len) len = b - a;
 	}
 	for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(len, o); len = other > len ? other : len; } // one atomic per wave
 	if ((threadIdx.x & 63) == 0) atomicMax(out_max, len);
@@ -657,7 +656,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	HIP_TRY(hipEventRecord(e->ev[2], s));
 	// read lengths: MAX_READ_LEN 65535 (comp_seed.h:39; the reference aborts at main.cpp:83-86)
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, 3 * sizeof(unsigned long long), s));
-	hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(n_reads, 256)), dim3(256), 0, s, d_off, n_reads, e->d_ctr.p + 3, e->d_ctr.p + 4);
+	hipLaunchKernelGGL(max_len_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads, 256), (int64_t)e->n_cu * 8)), dim3(256), 0, s, d_off, n_reads, e->d_ctr.p + 3, e->d_ctr.p + 4);
 	HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if (e->h_ctr.p[4]) return fail(CS_EINVAL, "offsets are not non-decreasing");
@@ -705,8 +704,10 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 				int fast16 = cap >= 16 ? 1 : 0;
 				if (fast16) hipLaunchKernelGGL(sort_compact16_kernel, dim3(grid_for(nb * 16, 256)), dim3(256), 0, s, e->d_out.p, e->d_cnt.p, cap,
 				                               e->d_mem_off.p + b0, nb, e->d_mems.p);
-				hipLaunchKernelGGL(sort_compact2_kernel, dim3(grid_for(nb, 128)), dim3(128), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
-				                   e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p, fast16);
+				if (fast16) hipLaunchKernelGGL(sort_compact_wave_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
+				                               e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p);
+				else hipLaunchKernelGGL(sort_compact2_kernel, dim3(grid_for(nb, 128)), dim3(128), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
+				                        e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p, 0);
 				HIP_TRY(hipGetLastError());
 				total_mems = new_total;
 				continue;

@@ -1168,6 +1168,47 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 		dst[rank] = ma;
 	}
 }
+// The reads sort_compact16_kernel leaves out (more than 64 mems, or mems beyond `cap`: tandem arrays, repeats): one WAVE per
+// read.  A wave owns 64 consecutive reads, finds the heavy ones by ballot and rank-sorts each with all 64 lanes: lane j
+// owns mems j, j+64, ...; the keys of 64 mems at a time sit in registers and travel by shuffle.  (One lane per read made
+// this kernel as slow as its slowest read: 5 ms for a handful of reads with hundreds of mems.)
+__global__ __launch_bounds__(256) void sort_compact_wave_kernel(const OutMem *raw, const uint32_t *cnt, uint32_t cap, const OvfRec *ovf, const uint32_t *ovf_key,
+                                                                const uint32_t *ovf_idx, uint64_t n_ovf, const uint64_t *mem_off, int64_t n_reads, OutMem *mems)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int64_t r0 = w * 64 + lane;
+	const uint32_t n_mine = r0 < n_reads ? cnt[r0] : 0;
+	uint64_t heavy = __ballot(n_mine > 64 || n_mine > cap);
+	while (heavy) {
+		const int hs = __ffsll((long long)heavy) - 1; heavy &= heavy - 1;
+		const int64_t r = w * 64 + hs; const uint32_t n = __shfl(n_mine, hs);
+		const OutMem *src = raw + (size_t)r * cap;
+		OutMem *dst = mems + mem_off[r];
+		uint64_t olo = 0;
+		if (n > cap) { // lower bound of r among the sorted overflow keys
+			uint64_t lo = 0, hi = n_ovf;
+			while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ovf_key[mid] < (uint32_t)r) lo = mid + 1; else hi = mid; }
+			olo = lo;
+		}
+		for (uint32_t a0 = 0; a0 < n; a0 += 64) {
+			const uint32_t a = a0 + lane;
+			OutMem ma = {0, 0, 0, ~0ull};
+			if (a < n) ma = mem_at(src, cap, ovf, ovf_idx, olo, a);
+			uint32_t rank = 0;
+			for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+				const uint32_t b = b0 + lane;
+				const uint64_t kb = b < n ? mem_at(src, cap, ovf, ovf_idx, olo, b).info : ~0ull; // padding keys are never smaller
+				for (int j = 0; j < 64; ++j) {
+					const uint64_t kj = __shfl(kb, j);
+					rank += (kj < ma.info) || (kj == ma.info && b0 + (uint32_t)j < a);
+				}
+			}
+			if (a < n) dst[rank] = ma;
+		}
+	}
+}
+
 // Fast form of the same for the bulk: 16 lanes per read (4 reads per wave).  Up to 16 mems: lane a owns mem a; 17..64 mems
 // (repeat-rich reads): lane a owns mems a, a+16, a+32, a+48.  Each mem is read once (coalesced: 16 lanes x 32 B contiguous),
 // keys travel by shuffle, and every lane writes its mems at their ranks.  Reads with more than 64 mems, or whose mems
