@@ -154,7 +154,8 @@ def main():
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": pmc, "kernel": "smem_kernel" if fused else "SMEM stage = fwd_kernel + bwd_all_kernel launches of one pass",
+                           "traffic": pmc, "kernel": "smem_kernel" if fused else "SMEM stage = all fwd / bwd_win / bwd_win0 / bwd_wide / r2text / r3text launches of one pass",
+                           "traffic_GBps": (pmc / (kern_ms * 1e-3) / 1e9) if pmc else None,
                            "kernel_ms_per_launch": kern_ms, "launches": launches,
                            "algorithmic_bytes_per_read": per_read, "uncached_bytes_per_read": per_read_unc,
                            "bwt_extend_queries_per_read": st["bwt_queries"] / (args.reads * args.steps),

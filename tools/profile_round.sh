@@ -48,7 +48,7 @@ for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % tag, recursive=Tru
         k = r["Kernel_Name"]
         if r["Counter_Name"] == "FETCH_SIZE" and any(t in k for t in ("fwd_kernel", "bwd_", "r2text", "r3text", "sal_", "sort_compact")):
             per.append([int(r.get("Dispatch_Id", 0)), k.split("(")[0].split("::")[-1][:18], round(float(r["Counter_Value"]) / 1048576, 3)])
-        name = "fwd_kernel" if "fwd_kernel" in k else "bwd_win0_kernel" if "bwd_win0" in k else "bwd_win_kernel" if "bwd_win" in k else "r2text_kernel" if "r2text" in k else "bwd_all_kernel" if "bwd_all" in k else "bwd_wide_kernel" if "bwd_wide" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
+        name = "fwd_kernel" if "fwd_kernel" in k else "bwd_win0_kernel" if "bwd_win0" in k else "bwd_win_kernel" if "bwd_win" in k else "r2text_kernel" if "r2text" in k else "r3text_kernel" if "r3text" in k else "bwd_all_kernel" if "bwd_all" in k else "bwd_wide_kernel" if "bwd_wide" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
         if name and r["Counter_Name"] == "FETCH_SIZE":
             agg[name] += float(r["Counter_Value"]); n[name] += 1
 out = {k: {"FETCH_SIZE_KiB_sum": v, "dispatches": n[k]} for k, v in agg.items()}
