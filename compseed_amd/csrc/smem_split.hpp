@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 	Intv ik = {0, 0, 0};
 	BaseReader<1> rd;
 	uint4 *lep = nullptr;
-	unsigned long long my_q = 0, my_hits = 0; uint32_t my_bt = 0, my_sw = 0;
+	uint32_t my_q = 0, my_hits = 0, my_sw = 0; // per-lane counters (a lane sees a few thousand extensions at most); bit 31 of my_sw: created a backward task
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
 	__shared__ uint4 sst[SST_ENTRIES];
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					if (A.win) cls = n == 0 ? 6u : n <= WIN_G32_LEPS ? 4u : n <= WIN_G64_LEPS ? 5u : 3u;
 					BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
 					A.bq[tslot] = bt;
-					++my_bt;
+					my_sw |= 0x80000000u;
 				}
 				active = false;
 			}
@@ -450,10 +450,10 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 		wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 	}
 	wave_push_finish(O, A);
-	atomicAdd(A.n_queries, my_q);
-	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
-	if (my_bt) atomicAdd(A.n_btasks, (unsigned long long)my_bt);
-	if (my_sw) atomicAdd(A.n_text_sweeps, (unsigned long long)my_sw);
+	atomicAdd(A.n_queries, (unsigned long long)my_q);
+	if (my_hits) atomicAdd(A.n_sst_hits, (unsigned long long)my_hits);
+	if (my_sw & 0x80000000u) atomicAdd(A.n_btasks, 1ull);
+	if (my_sw & 0x7fffffffu) atomicAdd(A.n_text_sweeps, (unsigned long long)(my_sw & 0x7fffffffu));
 }
 
 
@@ -1061,8 +1061,8 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, uint64_t
 // Round 3 (bwt_seed_strategy1, bwt.c:357-381; the loop of bwamem.c:253-262) after rounds 1 and 2, one lane per read.
 //
 // A round-3 seed starting at x is the shortest prefix [x, x+L), L >= min_seed_len + 1, with fewer than max_mem_intv
-// occurrences.  Where the read lies inside one of its own unique round-1 SMEMs [beg, end) -- text position P = SA[x0] --
-// the read IS the text, and for L = min_seed_len + 1 the answer is in the text arrays: rep[p] < L means the L-mer at p is
+// occurrences.  Where the read lies inside one of its own mems of rounds 1 and 2, [beg, end) -- an exact match of the text at
+// P = SA[x0], whichever of its occurrences that row is -- the read IS the text, and for L = min_seed_len + 1 the answer is in the text arrays: rep[p] < L means the L-mer at p is
 // unique (bi-interval = two inverse-suffix-array reads), otherwise a short walk over lcp[] counts its occurrences.  Only
 // where that does not apply (the seed would leave the SMEM, 20 or more occurrences, repeats without a unique SMEM) the
 // seed is computed on the FM index as before (jump table + extensions).  Same seeds, a fraction of the index reads:
@@ -1077,15 +1077,15 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, unsigned
 		const uint64_t rb = A.off[r]; const int len = (int)(A.off[r + 1] - rb);
 		const uint32_t nm0 = A.out_cnt[r] < A.cap ? A.out_cnt[r] : A.cap; // the mems of rounds 1 and 2 (this lane appends its own behind them)
 		const OutMem *mine = A.out + (size_t)r * A.cap;
-		int cb = 0, ce = 0; uint64_t cp = 0; // the unique SMEM the cursor is in: [cb, ce) at text position cp
+		int cb = 0, ce = 0; uint64_t cp = 0; // the mem the cursor is in: [cb, ce) at text position cp
 		int x = 0;
 		while (x < len) {
 			if (A.seq[rb + (uint64_t)x] > 3) { ++x; continue; }
-			if (!(x >= cb && x + k1 <= ce)) { // look for a unique SMEM that covers [x, x + k1)
+			if (!(x >= cb && x + k1 <= ce)) { // look for a mem that covers [x, x + k1)
 				cb = ce = 0;
 				for (uint32_t a = 0; a < nm0; ++a) {
 					const uint64_t info = mine[a].info; const int mb = (int)(info >> 32), me = (int)(uint32_t)info;
-					if (mine[a].x2 == 1 && x >= mb && x + k1 <= me) { cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0); break; }
+					if (x >= mb && x + k1 <= me) { cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0); break; } // any occurrence will do
 				}
 			}
 			if (x >= cb && x + k1 <= ce && ix.rep) {
