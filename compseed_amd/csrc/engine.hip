@@ -91,7 +91,7 @@ struct cs_engine {
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
 	DevBuf<uint32_t> d_fsa32; DevBuf<uint64_t> d_fsa64; // full suffix array (one of the two)
 	DevBuf<uint32_t> d_text2, d_isa32; DevBuf<uint64_t> d_isa64; // text mode: 2-bit text + inverse suffix array
-	DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
+	DevBuf<uint32_t> d_cnt_snap; DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
 	// inputs
 	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
 	// SMEM stage
@@ -371,7 +371,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
@@ -569,6 +569,21 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	};
 	bool r3_launched = false;
 	if (r3_async && r3_after <= 0) { CS_TRY(launch_r3()); r3_launched = true; }
+	// r3text_kernel runs on the second stream beside the late iterations (from the 4th on they carry < 3 % of the tasks but
+	// still cost a launch chain and a host round trip each); it works from a snapshot of the mem counts
+	const int r3t_iter = getenv("CS_R3_TEXT_ITER") ? atoi(getenv("CS_R3_TEXT_ITER")) : 3;
+	bool r3t_launched = false;
+	if (r3_text) CS_TRY(e->d_cnt_snap.reserve((size_t)nb + 1));
+	auto launch_r3text = [&]() -> int {
+		HIP_TRY(hipEventRecord(e->ev_r3a, s));
+		HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_r3a, 0));
+		HIP_TRY(hipMemcpyAsync(e->d_cnt_snap.p, e->d_cnt.p, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream2));
+		hipLaunchKernelGGL(r3text_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 16, ((uint64_t)nb + 255) / 256)), dim3(256), 0, e->stream2, A,
+		                   (const uint32_t *)e->d_cnt_snap.p, C + 15);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
+		return CS_OK;
+	};
 	uint64_t n_f = (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
 		A.fq_next = nxt; A.aux_next = aux_nxt;
@@ -613,6 +628,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			                   (const unsigned long long *)(C + 1), C + 11, C + 12);
 			HIP_TRY(hipGetLastError());
 		}
+		if (r3_text && !r3t_launched && iter + 1 >= r3t_iter) { CS_TRY(launch_r3text()); r3t_launched = true; }
 		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4); return 1; }
@@ -622,12 +638,9 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		std::swap(cur, nxt); std::swap(aux_cur, aux_nxt);
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
-	if (r3_text) {
-		hipLaunchKernelGGL(r3text_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 16, ((uint64_t)nb + 255) / 256)), dim3(256), 0, s, A, C + 15);
-		HIP_TRY(hipGetLastError());
-	}
+	if (r3_text && !r3t_launched) { CS_TRY(launch_r3text()); r3t_launched = true; }
 	if (r3_async && !r3_launched) { CS_TRY(launch_r3()); r3_launched = true; }
-	if (r3_async) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
+	if (r3_async || r3_text) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
 	HIP_TRY(hipEventRecord(e->ev[1], s));
 	HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));

@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, uint64_t
 // where that does not apply (the seed would leave the SMEM, 20 or more occurrences, repeats without a unique SMEM) the
 // seed is computed on the FM index as before (jump table + extensions).  Same seeds, a fraction of the index reads:
 // on the bench workload round 3 was the largest single consumer of HBM traffic.
-__global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, unsigned long long *n_text_seeds)
+// cnt_snap: the per-read mem counts at a moment when every entry below them was complete (a copy taken between launches):
+// the kernel may run beside the last, thin iterations of rounds 1/2, which keep appending to the same lists.  A read that is
+// still being worked on simply finds fewer covering mems and takes more of its seeds from the index.
+__global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const uint32_t *cnt_snap, unsigned long long *n_text_seeds)
 {
 	const DevIndex &ix = A.ix;
 	const int k1 = A.min_seed_len + 1;
@@ -1075,7 +1078,7 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, unsigned
 	unsigned long long my_q = 0, my_hits = 0, my_text = 0;
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
 		const uint64_t rb = A.off[r]; const int len = (int)(A.off[r + 1] - rb);
-		const uint32_t nm0 = A.out_cnt[r] < A.cap ? A.out_cnt[r] : A.cap; // the mems of rounds 1 and 2 (this lane appends its own behind them)
+		const uint32_t nm0 = cnt_snap[r] < A.cap ? cnt_snap[r] : A.cap; // the mems of rounds 1 and 2 known to be complete
 		const OutMem *mine = A.out + (size_t)r * A.cap;
 		int cb = 0, ce = 0; uint64_t cp = 0; // the mem the cursor is in: [cb, ce) at text position cp
 		int x = 0;
