@@ -130,6 +130,27 @@ def test_sample_is_bit_exact_vs_oracle(world):
     assert np.array_equal(r.seeds[: int(r.seed_off[n])], want["seeds"])
 
 
+@pytest.mark.parametrize("kw", [dict(k=15), dict(k=16, y=100), dict(k=17, r=1.0), dict(k=18, s=1), dict(k=19, c=50), dict(k=19, y=0),
+                                dict(k=19, y=5, r=1.2), dict(k=20), dict(k=25, r=1.1), dict(k=12, y=8)])
+def test_parameter_sweep_shortcuts_on_off_and_oracle(world, kw):
+    """every -k/-r/-y/-c/-s combination goes three ways: all shortcuts on (window scheme for 15 <= k <= 19, text arrays),
+    everything off (`sst_mode=0`: the literal sweep), and the CPU oracle; reads include Ns and 1 % substitutions"""
+    ca, eng = world["ca"], world["eng"]
+    n = 40000
+    hb, ho = world["bases"][: n * 150], world["off"][: n + 1]
+    on = eng.seed_batch(hb, ho, ca.Params(**kw))
+    off = eng.seed_batch(hb, ho, ca.Params(sst_mode=0, **kw))
+    assert np.array_equal(on.mem_off, off.mem_off) and np.array_equal(on.mems, off.mems)
+    assert np.array_equal(on.seed_off, off.seed_off) and np.array_equal(on.seeds, off.seeds)
+    bw, sa = world["ix"].arrays()
+    v = world["ix"].view
+    o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
+    m = 8000
+    want = o.seed_batch(hb[: m * 150], ho[: m + 1], _oracle.make_params(**kw), mode=1, threads=8)
+    assert np.array_equal(on.mem_off[: m + 1], want["mem_off"]) and np.array_equal(on.mems[: int(on.mem_off[m])], want["mems"])
+    assert np.array_equal(on.seeds[: int(on.seed_off[m])], want["seeds"])
+
+
 def test_full_baseline_size_properties():
     """BASELINE configs[1] shape: hg19-size index, 10 M x 150 bp reads, defaults; cheap size-independent checks on device
     results without copying 5 GB back: counts, sortedness, filters, and a checksum that must not change between two runs."""
