@@ -225,11 +225,11 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	CS_TRY(e->d_sa.reserve((size_t)v->n_sa));
 	HIP_TRY(hipMemcpyAsync(e->d_sa.p, v->sa, (size_t)v->n_sa * 8, hipMemcpyHostToDevice, e->stream));
 	// one-time conversion of the 2-bit packed bases of every block into bit planes (fm_device.hpp)
-	CS_TRY(e->d_sctr.reserve(16));
-	CS_TRY(e->h_sctr.reserve(16));
+	CS_TRY(e->d_sctr.reserve(32));
+	CS_TRY(e->h_sctr.reserve(32));
 	CS_TRY(e->d_sst2.reserve(SST2_ENTRIES));
 	HIP_TRY(hipMemsetAsync(e->d_sst2.p, 0xff, SST2_ENTRIES * sizeof(uint4), e->stream)); // empty second-level SST
-	HIP_TRY(hipMemsetAsync(e->d_sctr.p, 0, 16 * sizeof(unsigned long long), e->stream));
+	HIP_TRY(hipMemsetAsync(e->d_sctr.p, 0, 32 * sizeof(unsigned long long), e->stream));
 	hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, e->stream, e->d_bwt.p, n_blocks, e->d_sctr.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_sctr.p, e->d_sctr.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
@@ -526,7 +526,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	CS_TRY(e->d_bq.reserve(chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
 	CS_TRY(e->d_ovfrec.reserve(ovf_cap));
 	unsigned long long *C = e->d_sctr.p, *H = e->h_sctr.p; // [0] task ctr [1] next-queue length [2..5] backward queues [6] overflow mems [7] error [8] queries
-	HIP_TRY(hipMemsetAsync(C, 0, 16 * sizeof(unsigned long long), s));
+	HIP_TRY(hipMemsetAsync(C, 0, 32 * sizeof(unsigned long long), s));
 	HIP_TRY(hipMemsetAsync(e->d_cnt.p, 0, ((size_t)nb + 1) * sizeof(uint32_t), s));
 
 	SplitArgs A;
@@ -624,25 +624,27 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			c0 += cn;
 		}
 		if (r2text) { // re-seeding calls of unique SMEMs pushed by this iteration: answer from the text what the text can answer
-			hipLaunchKernelGGL(r2text_kernel, dim3((unsigned)e->n_cu * 8), dim3(256), 0, s, A, nxt, (const uint64_t *)aux_nxt,
-			                   (const unsigned long long *)(C + 1), C + 11, C + 12);
+			// ... and copy what is left, without the no-op slots, into the queue this iteration has just consumed
+			HIP_TRY(hipMemsetAsync(C + 16, 0, sizeof(unsigned long long), s));
+			hipLaunchKernelGGL(r2text_kernel, dim3((unsigned)e->n_cu * 8), dim3(256), 0, s, A, (const uint64_t *)nxt, (const uint64_t *)aux_nxt,
+			                   (const unsigned long long *)(C + 1), C + 11, C + 12, cur, C + 16);
 			HIP_TRY(hipGetLastError());
 		}
 		if (r3_text && !r3t_launched && iter + 1 >= r3t_iter) { CS_TRY(launch_r3text()); r3t_launched = true; }
-		HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4); return 1; }
-		n_f = H[1];
+		n_f = r2text ? H[16] : H[1];
 		if (getenv("CS_VERBOSE")) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[11], H[12]);
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
-		std::swap(cur, nxt); std::swap(aux_cur, aux_nxt);
+		if (!r2text) { std::swap(cur, nxt); std::swap(aux_cur, aux_nxt); } // (r2text_kernel has compacted the next queue into `cur`)
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
 	if (r3_text && !r3t_launched) { CS_TRY(launch_r3text()); r3t_launched = true; }
 	if (r3_async && !r3_launched) { CS_TRY(launch_r3()); r3_launched = true; }
 	if (r3_async || r3_text) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
 	HIP_TRY(hipEventRecord(e->ev[1], s));
-	HIP_TRY(hipMemcpyAsync(H, C, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 	e->st.seed_kernel_launches++;

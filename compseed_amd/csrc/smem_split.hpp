@@ -1039,22 +1039,44 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 	if (ne > 1) emit_mem(A, r, i1, (uint32_t)(beg + o1), (uint32_t)(beg + o1 + v1));
 	return true;
 }
-// one lane per slot of the next forward queue; answered calls are replaced by no-ops
-__global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, uint64_t *fq, const uint64_t *aux, const unsigned long long *n_ptr,
-                                                     unsigned long long *n_done, unsigned long long *n_left)
+// One lane per slot of the next forward queue.  Calls that are answered drop out; everything else is copied, without the
+// no-op padding, to `fq_out` (the queue the finished iteration has consumed), so the next launches see a dense queue.
+__global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const uint64_t *fq, const uint64_t *aux, const unsigned long long *n_ptr,
+                                                     unsigned long long *n_done, unsigned long long *n_left, uint64_t *fq_out, unsigned long long *n_out)
 {
 	uint64_t n = *n_ptr; if (n > A.fq_cap) n = A.fq_cap;
+	const uint32_t lane = threadIdx.x & 63u;
 	unsigned long long done = 0, left = 0;
-	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
-		uint64_t task = fq[t];
-		if ((uint32_t)(task >> 62) != TK_ROUND2 || ((task >> 48) & 0x3fffu) != 2u) continue;
-		uint64_t a = aux[t];
-		uint32_t r = (uint32_t)task; int pivot = (int)((task >> 32) & 0xffffu);
-		int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
-		if (r2_by_text(A, r, a & ((1ull << 37) - 1ull), beg, end, pivot)) { fq[t] = FTASK_NONE; ++done; } else ++left;
+	// a wave takes 256 consecutive slots at a time (one atomic on the output counter per 256 slots)
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	for (uint64_t t0 = wave * 256; t0 < n; t0 += n_waves * 256) { // wave-uniform
+		uint64_t task[4]; uint64_t km[4]; uint32_t total = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint64_t t = t0 + (uint64_t)(64 * j) + lane;
+			task[j] = t < n ? fq[t] : FTASK_NONE;
+			if ((uint32_t)(task[j] >> 62) == TK_ROUND2 && ((task[j] >> 48) & 0x3fffu) == 2u) {
+				uint64_t a = aux[t];
+				uint32_t r = (uint32_t)task[j]; int pivot = (int)((task[j] >> 32) & 0xffffu);
+				int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
+				if (r2_by_text(A, r, a & ((1ull << 37) - 1ull), beg, end, pivot)) { task[j] = FTASK_NONE; ++done; } else ++left;
+			}
+			km[j] = __ballot(task[j] != FTASK_NONE);
+			total += (uint32_t)__popcll(km[j]);
+		}
+		if (total) {
+			unsigned long long base = 0;
+			if (lane == 0) base = atomicAdd(n_out, (unsigned long long)total);
+			base = __shfl(base, 0);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (task[j] != FTASK_NONE) fq_out[base + (uint64_t)__popcll(km[j] & ((1ull << lane) - 1ull))] = task[j];
+				base += (uint64_t)__popcll(km[j]);
+			}
+		}
 	}
 	for (int o = 32; o > 0; o >>= 1) { done += __shfl_xor(done, o); left += __shfl_xor(left, o); }
-	if ((threadIdx.x & 63u) == 0) { if (done) atomicAdd(n_done, done); if (left) atomicAdd(n_left, left); }
+	if (lane == 0) { if (done) atomicAdd(n_done, done); if (left) atomicAdd(n_left, left); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
