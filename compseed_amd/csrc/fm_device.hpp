@@ -197,20 +197,20 @@ __device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int 
 	uint32_t nk = ((uint32_t)rk & OCC_MASK) + 1, nl = ((uint32_t)rl & OCC_MASK) + 1, k1, k2, k3, l1, l2, l3;
 	count_cgt(bk, nk, k1, k2, k3);
 	count_cgt(bl, nl, l1, l2, l3);
-	uint64_t tk0 = (uint64_t)bk.cnt.x + (nk - k1 - k2 - k3), tl0 = (uint64_t)bl.cnt.x + (nl - l1 - l2 - l3);
-	uint64_t tk1 = (uint64_t)bk.cnt.y + k1, tl1 = (uint64_t)bl.cnt.y + l1;
-	uint64_t tk2 = (uint64_t)bk.cnt.z + k2, tl2 = (uint64_t)bl.cnt.z + l2;
-	uint64_t tk3 = (uint64_t)bk.cnt.w + k3, tl3 = (uint64_t)bl.cnt.w + l3;
-	uint64_t s0 = tl0 - tk0, s1 = tl1 - tk1, s2 = tl2 - tk2, s3 = tl3 - tk3;
-	uint64_t tkc = sel4(c, tk0, tk1, tk2, tk3);
-	uint64_t sc  = sel4(c, s0, s1, s2, s3);
+	// Everything up to the final coordinates fits 32 bits: no base occurs 2^32 times (checked at upload), so Occ values
+	// and child sizes are below 2^32 and their differences are exact modulo 2^32.  (This function is the VALU hot spot of
+	// the backward kernels, which are issue-bound: 64-bit adds and selects cost two instructions each.)
+	const uint32_t tk0 = bk.cnt.x + (nk - k1 - k2 - k3), tk1 = bk.cnt.y + k1, tk2 = bk.cnt.z + k2, tk3 = bk.cnt.w + k3;
+	const uint32_t s0 = bl.cnt.x + (nl - l1 - l2 - l3) - tk0, s1 = bl.cnt.y + l1 - tk1, s2 = bl.cnt.z + l2 - tk2, s3 = bl.cnt.w + l3 - tk3;
+	const uint32_t tkc = c == 0 ? tk0 : c == 1 ? tk1 : c == 2 ? tk2 : tk3;
+	const uint32_t sc  = c == 0 ? s0 : c == 1 ? s1 : c == 2 ? s2 : s3;
 	uint64_t l2c = sel4(c, ix.L2[0], ix.L2[1], ix.L2[2], ix.L2[3]);
 	// children of larger bases sit in front of child c on the shifted coordinate (cascade of bwt.c:271-274)
-	uint64_t above = (c < 3 ? s3 : 0) + (c < 2 ? s2 : 0) + (c < 1 ? s1 : 0);
+	uint64_t above = (uint64_t)(c < 3 ? s3 : 0u) + (uint64_t)(c < 2 ? s2 : 0u) + (uint64_t)(c < 1 ? s1 : 0u);
 	uint64_t ya = l2c + 1 + tkc;
 	uint64_t yb = xb + ((xa <= ix.primary && xa + ik.x2 - 1 >= ix.primary) ? 1 : 0) + above;
 	Intv o;
-	o.x0 = IS_BACK ? ya : yb; o.x1 = IS_BACK ? yb : ya; o.x2 = sc;
+	o.x0 = IS_BACK ? ya : yb; o.x1 = IS_BACK ? yb : ya; o.x2 = (uint64_t)sc;
 	return o;
 }
 
