@@ -85,17 +85,14 @@ __device__ __forceinline__ Block load_block(const DevIndex &ix, uint64_t rec)
 // occurrences of C, G, T among the first `nb` (1..64) bases of a record
 __device__ __forceinline__ void count_cgt(const Block &k, uint32_t nb, uint32_t &c1, uint32_t &c2, uint32_t &c3)
 {
-	const uint32_t L[2] = {k.pl.x, k.pl.y}, H[2] = {k.pl.z, k.pl.w};
-	c1 = c2 = c3 = 0;
-#pragma unroll
-	for (int w = 0; w < 2; ++w) {
-		int t = (int)nb - 32 * w;                                 // bases wanted from this word
-		uint32_t m = t >= 32 ? 0xffffffffu : (t <= 0 ? 0u : ((1u << t) - 1u));
-		uint32_t lo = L[w] & m, hi = H[w] & m;
-		c1 += __builtin_popcount(lo & ~hi);                       // 01 = C
-		c2 += __builtin_popcount(hi & ~lo);                       // 10 = G
-		c3 += __builtin_popcount(lo & hi);                        // 11 = T
-	}
+	// masks of the first nb bases in the two 32-base words; popcounts accumulate (v_bcnt_u32_b32 adds for free):
+	// T = lo & hi, C = lo without T, G = hi without T
+	const uint32_t m0 = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+	const uint32_t m1 = nb <= 32 ? 0u : (nb >= 64 ? 0xffffffffu : ((1u << (nb - 32)) - 1u));
+	const uint32_t lo0 = k.pl.x & m0, lo1 = k.pl.y & m1, hi0 = k.pl.z & m0, hi1 = k.pl.w & m1;
+	c3 = __builtin_popcount(lo0 & hi0) + __builtin_popcount(lo1 & hi1);
+	c1 = __builtin_popcount(lo0) + __builtin_popcount(lo1) - c3;
+	c2 = __builtin_popcount(hi0) + __builtin_popcount(hi1) - c3;
 }
 
 // counts of A,C,G,T in rows [0, row] given the block that holds `row` (row already primary-adjusted)

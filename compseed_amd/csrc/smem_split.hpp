@@ -1115,6 +1115,42 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 			}
 			if (x >= cb && x + k1 <= ce && ix.rep) {
 				const uint64_t p = cp + (uint64_t)(x - cb);
+				// Inside a mem the next seeds start k1 apart as long as each k1-mer is unique, so up to four of them are resolved
+				// at once: four rep[] bytes, then eight independent inverse-SA reads, one counter update for the four mems.
+				{
+					constexpr int SPEC = 4;
+					int ns = (ce - x) / k1; if (ns > SPEC) ns = SPEC;
+					uint32_t vj[SPEC];
+#pragma unroll
+					for (int j = 0; j < SPEC; ++j) vj[j] = j < ns ? (uint32_t)ix.rep[p + (uint64_t)(j * k1)] : 255u;
+					int nu = 0; // leading unique k1-mers
+#pragma unroll
+					for (int j = 0; j < SPEC; ++j) if (nu == j && vj[j] < (uint32_t)k1) nu = j + 1;
+					if (nu > 0) {
+						uint64_t a0[SPEC], a1[SPEC];
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							const uint64_t pj = p + (uint64_t)(j * k1);
+							a0[j] = j < nu ? isa_direct(ix, pj) : 0; a1[j] = j < nu ? isa_direct(ix, ix.seq_len - (pj + (uint64_t)k1)) : 0;
+						}
+						const uint32_t k0 = atomicAdd(&A.out_cnt[r], (uint32_t)nu);
+#pragma unroll
+						for (int j = 0; j < SPEC; ++j) {
+							if (j < nu) {
+								OutMem m = {a0[j], a1[j], 1, (uint64_t)(uint32_t)(x + j * k1) << 32 | (uint32_t)(x + (j + 1) * k1)};
+								const uint32_t kk = k0 + (uint32_t)j;
+								if (kk < A.cap) A.out[(size_t)r * A.cap + kk] = m;
+								else {
+									unsigned long long sl = atomicAdd(A.ovf_cnt, 1ull);
+									if (sl < A.ovf_cap) { OvfRec o = {m, (uint32_t)r, 0}; A.ovf[sl] = o; } else atomicMax(A.err, 1ull);
+								}
+							}
+						}
+						my_q += (unsigned)(nu * (k1 - 1)); my_hits += (unsigned)(nu * (k1 - 1)); my_text += (unsigned)nu;
+						x += nu * k1;
+						continue;
+					}
+				}
 				const uint32_t v = ix.rep[p];
 				Intv iv = {0, 0, 0}; bool ok = false;
 				if (v < (uint32_t)k1) { iv.x0 = isa_direct(ix, p); iv.x1 = isa_direct(ix, ix.seq_len - (p + (uint64_t)k1)); iv.x2 = 1; ok = true; }
