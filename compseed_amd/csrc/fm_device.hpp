@@ -87,8 +87,8 @@ __device__ __forceinline__ void count_cgt(const Block &k, uint32_t nb, uint32_t 
 {
 	// masks of the first nb bases in the two 32-base words; popcounts accumulate (v_bcnt_u32_b32 adds for free):
 	// T = lo & hi, C = lo without T, G = hi without T
-	const uint32_t m0 = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
-	const uint32_t m1 = nb <= 32 ? 0u : (nb >= 64 ? 0xffffffffu : ((1u << (nb - 32)) - 1u));
+	const uint64_t m = ~0ull >> (64u - nb); // nb in 1..64: one 64-bit shift instead of two compare/select chains
+	const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
 	const uint32_t lo0 = k.pl.x & m0, lo1 = k.pl.y & m1, hi0 = k.pl.z & m0, hi1 = k.pl.w & m1;
 	c3 = __builtin_popcount(lo0 & hi0) + __builtin_popcount(lo1 & hi1);
 	c1 = __builtin_popcount(lo0) + __builtin_popcount(lo1) - c3;
