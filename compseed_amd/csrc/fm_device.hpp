@@ -46,7 +46,8 @@ struct DevIndex {
 	const uint8_t *rep;
 };
 
-struct Intv { uint64_t x0, x1, x2; };
+struct Intv { uint64_t x0, x1; uint32_t x2; }; // the search's bi-interval; x2 < 2^32: no base occurs 2^32 times (checked at upload)
+struct Intv64 { uint64_t x0, x1, x2; };           // the primitive entry points take any interval, e.g. the whole text
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)hi << 32 | lo; }
 
@@ -150,7 +151,7 @@ __device__ __forceinline__ Intv set_intv(const DevIndex &ix, int c)
 }
 
 // bwt_extend (bwt.c:262-275), all four children
-__device__ __forceinline__ int extend4(const DevIndex &ix, const Intv &ik, bool is_back, Intv ok[4])
+__device__ __forceinline__ int extend4(const DevIndex &ix, const Intv64 &ik, bool is_back, Intv64 ok[4])
 {
 	uint64_t xa = is_back ? ik.x0 : ik.x1, xb = is_back ? ik.x1 : ik.x0;
 	uint64_t tk[4], tl[4];

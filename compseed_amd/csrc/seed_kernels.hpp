@@ -55,14 +55,14 @@ __device__ __forceinline__ uint4 pack_lep(const Intv &v, uint32_t end)
 {
 	uint4 e;
 	e.x = (uint32_t)v.x0; e.y = (uint32_t)v.x1; e.z = (uint32_t)v.x2;
-	e.w = (uint32_t)(v.x0 >> 32) | (uint32_t)(v.x1 >> 32) << 5 | (uint32_t)(v.x2 >> 32) << 10 | end << 16;
+	e.w = (uint32_t)(v.x0 >> 32) | (uint32_t)(v.x1 >> 32) << 5 | end << 16; // (bits 10..14 held the top of a 37-bit size; sizes are 32-bit)
 	return e;
 }
 __device__ __forceinline__ void unpack_lep(const uint4 &e, Intv &v, uint32_t &end)
 {
 	v.x0 = (uint64_t)(e.w & 31u) << 32 | e.x;
 	v.x1 = (uint64_t)((e.w >> 5) & 31u) << 32 | e.y;
-	v.x2 = (uint64_t)((e.w >> 10) & 31u) << 32 | e.z;
+	v.x2 = e.z;
 	end = e.w >> 16;
 }
 
@@ -342,16 +342,18 @@ __global__ void extend_kernel(const DevIndex ix, const OutMem *ik, const uint8_t
 {
 	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n) return;
-	Intv v = {ik[t].x0, ik[t].x1, ik[t].x2}, o[4];
-	extend4(ix, v, is_back[t] != 0, o);
+	Intv64 v64 = {ik[t].x0, ik[t].x1, ik[t].x2}, o[4];
+	extend4(ix, v64, is_back[t] != 0, o);
+	const bool small = ik[t].x2 < (1ull << 32);            // the single-child forms serve the search: sizes below 2^32
+	Intv v = {ik[t].x0, ik[t].x1, (uint32_t)ik[t].x2};
 	for (int c = 0; c < 4; ++c) {
 		OutMem m = {o[c].x0, o[c].x1, o[c].x2, 0};
 		ok[4 * t + c] = m;
 		// the single-child paths used by the search must agree with the four-child one
 		Intv o1 = extend1_rt(ix, v, is_back[t] != 0, c);
 		Intv o2 = is_back[t] ? extend1<true>(ix, v, c) : extend1<false>(ix, v, c);
-		if (v.x0 != 0 && v.x1 != 0 && (o2.x0 != o[c].x0 || o2.x1 != o[c].x1 || o2.x2 != o[c].x2)) ok[4 * t + c].info = 2;
-		if (o1.x0 != o[c].x0 || o1.x1 != o[c].x1 || o1.x2 != o[c].x2) ok[4 * t + c].info = 1;
+		if (small && v.x0 != 0 && v.x1 != 0 && (o2.x0 != o[c].x0 || o2.x1 != o[c].x1 || o2.x2 != o[c].x2)) ok[4 * t + c].info = 2;
+		if (small && (o1.x0 != o[c].x0 || o1.x1 != o[c].x1 || o1.x2 != o[c].x2)) ok[4 * t + c].info = 1;
 	}
 }
 __global__ void sa_kernel(const DevIndex ix, const uint64_t *k, uint64_t *sa, int64_t n)
