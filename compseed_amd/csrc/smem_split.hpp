@@ -598,17 +598,28 @@ __device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, u
 	const int k = A.min_seed_len, jk = A.jump_k;
 	const int te = x + 1 + (int)gl;
 	if ((int)gl >= k - 1 || te > ret || te - k < 0) return false;
-	// the jump_k bases [te - jk, te) out of three aligned 8-byte words of the read
+	// the jump_k (<= 16) bases [te - jk, te) out of three aligned 8-byte words of the read, packed 2 bits each without a
+	// per-base loop: funnel the bytes into two words, squeeze each word's eight 2-bit codes together (three shift-or-mask
+	// steps), then reverse the order of the 2-bit groups (first base most significant, as jump_fill_kernel numbers k-mers)
 	const uint64_t a = rb + (uint64_t)(te - jk), a0 = a & ~7ull;
 	const uint64_t *w = reinterpret_cast<const uint64_t *>(A.seq + a0);
-	uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
-	uint32_t code = 0, bad = 0;
-	for (int q = 0; q < jk; ++q) {
-		uint32_t o = (uint32_t)(a - a0) + (uint32_t)q;
-		uint64_t word = o < 8 ? w0 : o < 16 ? w1 : w2;
-		uint32_t b = (uint32_t)(word >> ((o & 7u) << 3)) & 0xffu;
-		bad |= b; code = code << 2 | (b & 3u);
-	}
+	const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+	const uint32_t sh = (uint32_t)(a - a0) << 3;
+	uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+	uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
+	if (jk < 8) { lo &= (1ull << (8 * jk)) - 1ull; hi = 0; }
+	else if (jk < 16) hi &= (1ull << (8 * (jk - 8))) - 1ull;
+	const uint32_t bad = ((lo | hi) & 0xFCFCFCFCFCFCFCFCull) ? 4u : 0u;
+	auto squeeze = [](uint64_t v) -> uint32_t {
+		v &= 0x0303030303030303ull;
+		v = (v | (v >> 6)) & 0x000F000F000F000Full;
+		v = (v | (v >> 12)) & 0x000000FF000000FFull;
+		return (uint32_t)((v | (v >> 24)) & 0xFFFFull);
+	};
+	uint32_t fwd = squeeze(lo) | squeeze(hi) << 16;            // base q at bits 2q
+	uint32_t rv = __brev(fwd);                                   // group q at 2(15-q), its two bits swapped
+	rv = ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
+	const uint32_t code = rv >> (32 - 2 * jk);
 	if (bad > 3) return false; // an ambiguous base inside the window: this end cannot reach min_seed_len
 	uint32_t dummy; unpack_lep(A.jump[code], e, dummy);
 	my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
@@ -844,18 +855,65 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 // matches are all chance matches) are the bulk, and all their work is the 18 window lookups, of which 98 % die within
 // four extensions.  They get a kernel of their own that packs three calls into a wave (54 of 64 lanes busy) instead of
 // one call per 32-lane group: a wave owns 64 consecutive slots, finds this class by ballot and works through it three
-// at a time.  Nothing is carried between rounds, so no dispenser and no atomics on the task side.
+// at a time.  Each round is the jump-table read plus exactly min_seed_len - jump_k extensions in lockstep; the few
+// lanes that still match after that are PARKED in LDS, and only when enough of them have gathered (or the 64 slots are
+// done) does the wave walk them on to their ends, all together, and apply the first-survivor rule per call.  (Walking
+// them inside their round kept the whole wave waiting for one or two lanes a third of the time; the kernel is VALU-bound.)
+// No dispenser and no atomics on the task side.
+struct WinPark { uint4 iv; int32_t s; uint32_t r; uint16_t mk; uint8_t key, g; uint32_t pad; }; // 32 B: a match that reached min_seed_len
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void bwd_win0_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
+__global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
 {
 	if (*A.n_btasks == 0) return;
+	constexpr int PARK = 64;
 	__shared__ uint8_t rank2lane[BLOCK / 64][64];
+	__shared__ WinPark park[BLOCK / 64][PARK];
+	__shared__ int32_t park_f[BLOCK / 64][PARK];
 	const DevIndex &ix = A.ix;
 	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
 	const uint32_t seg = lane / WIN_LANES, gl = lane - seg * WIN_LANES;      // three segments of 18 lanes; lanes 54..63 idle
-	const uint64_t segmask = seg < 3 ? ((1ull << WIN_LANES) - 1ull) << (seg * WIN_LANES) : 0ull;
+	const int kx = A.min_seed_len - A.jump_k;                                // extensions from the jump_k-mer to min_seed_len
 	WaveOut O = {0, 0};
 	unsigned long long my_q = 0, my_hits = 0;
+	int npark = 0; // wave-uniform
+	// walk the parked matches to their ends and report (bwd_win_run's rule, the lanes of a call found by their key)
+	auto flush = [&]() {
+		const bool mine = (int)lane < npark;
+		Intv e = {0, 0, 0}; uint32_t pend = 0, r = 0, mk = 0, key = 0, g = 0; int s = 0, f = 0x7fffffff; uint64_t rb = 0;
+		if (mine) {
+			const WinPark p = park[wv][lane];
+			unpack_lep(p.iv, e, pend); s = p.s; r = p.r; mk = p.mk; key = p.key; g = p.g;
+			rb = A.off[r];
+		}
+		const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
+		bool walking = mine;
+		while (__ballot(walking)) {
+			if (walking) {
+				uint32_t b = s < 0 ? 4u : (uint32_t)A.seq[rb + (uint64_t)s];
+				if (b > 3) { f = s; walking = false; }
+				else {
+					Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
+				}
+			}
+		}
+		if (mine) park_f[wv][lane] = f;
+		__builtin_amdgcn_wave_barrier();
+		bool emit = mine;
+		if (mine) { // the nearest longer match of the same call among the parked ones
+			uint32_t best_g = 256; int best_f = 0;
+			for (int q = 0; q < npark; ++q) {
+				const uint32_t kq = park[wv][q].key, gq = park[wv][q].g;
+				if (kq == key && gq > g && gq < best_g) { best_g = gq; best_f = park_f[wv][q]; }
+			}
+			emit = best_g == 256 || f < best_f;
+		}
+		uint64_t push0 = FTASK_NONE, aux0 = AUX_NONE;
+		if (emit) push0 = emit_smem(A, r, kind, e, f + 1, pend, aux0);
+		wave_push<64>(O, push0 != FTASK_NONE, push0, A, aux0);
+		__builtin_amdgcn_wave_barrier();
+		npark = 0;
+	};
 	const uint64_t n_batches = (n_tasks + 63) / 64, wstride = (uint64_t)gridDim.x * (BLOCK / 64);
 	for (uint64_t bch = (uint64_t)blockIdx.x * (BLOCK / 64) + wv; bch < n_batches; bch += wstride) { // wave-uniform
 		const uint64_t slot = bch * 64 + lane;
@@ -868,6 +926,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_win0_kernel(const SplitArgs A, cons
 		if (is) rank2lane[wv][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
 		__builtin_amdgcn_wave_barrier();
 		for (int r0 = 0; r0 < cnt; r0 += 3) { // wave-uniform
+			if (npark > PARK - 3 * WIN_LANES) flush();
 			const int rank = r0 + (int)seg;
 			const bool job = seg < 3 && rank < cnt;
 			const int src = job ? (int)rank2lane[wv][rank] : (int)lane;
@@ -875,30 +934,31 @@ __global__ __launch_bounds__(BLOCK) void bwd_win0_kernel(const SplitArgs A, cons
 			const int x = __shfl((int)bt.x, src), ret = __shfl((int)bt.ret, src);
 			const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
 			const uint64_t rb = job ? A.off[r] : 0;
-			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0, f = 0x7fffffff;
-			const bool valid = job && win_lane_init(A, gl, rb, x, ret, min_intv, e, pend, s, my_q, my_hits);
-			bool walking = valid;
-			while (__ballot(walking)) {
-				if (walking) {
-					uint32_t b = s < 0 ? 4u : (uint32_t)A.seq[rb + (uint64_t)s];
-					if (b > 3) { f = s; walking = false; }
+			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0;
+			bool alive = job && win_lane_init(A, gl, rb, x, ret, min_intv, e, pend, s, my_q, my_hits);
+			for (int st = 0; st < kx; ++st) { // wave-uniform: the jump_k-mer grows to min_seed_len bases, or the lane drops out
+				if (alive) {
+					const uint32_t b = (uint32_t)A.seq[rb + (uint64_t)s];          // s >= 0: the window starts inside the read
+					if (b > 3) alive = false;
 					else {
 						Intv y = extend1<true>(ix, e, (int)b); ++my_q;
-						if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
+						if (y.x2 < min_intv) alive = false; else { e = y; --s; }
 					}
 				}
 			}
-			const uint64_t vm = __ballot(valid) & segmask;
-			const uint64_t higher = lane == 63 ? 0ull : vm & ~((2ull << lane) - 1ull);
-			const int hsrc = higher ? __ffsll((long long)higher) - 1 : (int)lane;
-			const int fn = __shfl(f, hsrc);
-			uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
-			if (valid && (higher == 0 || f < fn)) push0 = emit_smem(A, r, kind, e, f + 1, pend, aux0);
+			const uint64_t am = __ballot(alive);
+			if (alive) {
+				WinPark p; p.iv = pack_lep(e, pend); p.s = s; p.r = r; p.mk = (uint16_t)mk; p.key = (uint8_t)src; p.g = (uint8_t)gl; p.pad = 0;
+				park[wv][npark + __popcll(am & ((1ull << lane) - 1ull))] = p;
+			}
+			npark += __popcll(am);
+			uint64_t push1 = FTASK_NONE;
 			if (job && gl == 0 && kind == TK_ROUND1) push1 = chain_round1(A, r, ret, x);
-			wave_push<64>(O, push0 != FTASK_NONE, push0, A, aux0);
 			wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 		}
 		__builtin_amdgcn_wave_barrier();
+		// the parked matches of different 64-slot batches may share a key: settle them before the keys are reused
+		if (npark) flush();
 	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
