@@ -6,17 +6,18 @@
 // (a bare dependent chain of random 64-byte reads runs at 57 G lines/s, 3.6 TB/s; the fused kernel reached 35 % of
 // that), and 54 % of all bwt_extend calls belong to backward sweeps that extend ~9 independent intervals per step.
 //
-//   fwd_kernel   one LANE per task.  A task is the forward pass of one SMEM call (bwt.c:300-320) or the whole round-3
-//                chain of a read (bwt_seed_strategy1, bwt.c:358-379).  The loop body is one forward bwt_extend plus a
-//                compare; LEPs (intervals where the occurrence count changes) are streamed to a per-task list in HBM
-//                with fire-and-forget 16-byte stores.  No LDS, so occupancy is set by registers only.
-//   bwd_kernel   a GROUP of G lanes (16/32/64) per SMEM call.  Lane g holds LEP n-1-g in registers; every step of the
-//                backward sweep (bwt.c:325-345) extends ALL live intervals at once -- one memory round trip per read
-//                position instead of one per interval -- and the reference's sequential keep/emit rules are evaluated
-//                with a ballot and one shuffle: occurrence counts are monotone along the list (a longer match cannot
-//                occur more often), so the intervals that stop form a prefix, only the first of them can be a new
-//                SMEM, and "differs from the last kept size" is a comparison with the previous surviving lane.
-//   bwd_serial_kernel  the same sweep by one lane over the list in HBM, for the rare call with more than 64 LEPs.
+//   fwd_kernel   one LANE per task: the forward pass of one SMEM call (bwt.c:300-320), or the whole round-3 chain of a
+//                read when round 3 runs on the index only.  Starts from the k-mer jump table, leaves the index for the
+//                2-bit text once the match is unique, finishes calls whose sweep is trivial or can be read off the text.
+//   bwd_win0_kernel / bwd_win_kernel / bwd_wide_kernel   the backward sweeps under the window scheme (default): short match
+//                ends are settled through the jump table, stored LEPs walk in groups of 32/64 lanes on one clock.
+//   bwd_all_kernel   the literal sweep (bwt.c:325-345), a GROUP of G lanes (16/32/64) per call; lane g holds LEP n-1-g in
+//                registers; every step extends ALL live intervals at once and the reference's sequential keep/emit rules
+//                are evaluated with a ballot and one shuffle: occurrence counts are monotone along the list (a longer
+//                match cannot occur more often), so the intervals that stop form a prefix, only the first of them can be
+//                a new SMEM, and "differs from the last kept size" is a comparison with the previous surviving lane.
+//   r2text_kernel / r3text_kernel   re-seeding calls and round-3 seeds answered from the text-side arrays.
+//   (DESIGN.md section 4.2 states each shortcut and why it is exact.)
 //
 // Calls are chained through task queues in HBM: a finished backward sweep of round 1 enqueues the forward pass at the
 // next pivot (bwamem.c:226-236), and every emitted round-1 SMEM that is long and rare enough enqueues its re-seeding
@@ -992,43 +993,6 @@ __global__ __launch_bounds__(256) void bwd_wide_kernel(const SplitArgs A, const 
 	unsigned long long my_q = 0;
 	bwd_wide_run(A, bq, n_tasks, ctr, O, my_q);
 	wave_push_finish(O, A);
-	atomicAdd(A.n_queries, my_q);
-}
-
-// one lane, list in HBM, compacted in place (reference form of the sweep; kept for A/B tests of the wide path)
-__global__ void bwd_serial_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
-{
-	const DevIndex &ix = A.ix;
-	unsigned long long my_q = 0;
-	for (;;) {
-		unsigned long long t = atomicAdd(A.task_ctr, 1ull);
-		if (t >= n_tasks) break;
-		BTask bt = bq[t];
-		if (bt.cls != 3u) continue;
-		uint32_t r = bt.r, kind = bt.mi_kind >> 14, min_intv = bt.mi_kind & 0x3fffu;
-		uint4 *lep = A.lep + (size_t)t * A.lep_stride;
-		uint64_t rb = A.off[r];
-		int n = bt.n, lo = 0, nm = 0, last_start = 0;
-		for (int i = (int)bt.x - 1; i >= -1; --i) {
-			uint32_t b = i < 0 ? 4u : A.seq[rb + i];
-			int w = n; bool kept = false; uint64_t last_kept = 0;
-			for (int j = n - 1; j >= lo; --j) {
-				Intv p; uint32_t pend; unpack_lep(lep[j], p, pend);
-				Intv y = p;
-				if (b <= 3) { y = extend1<true>(ix, p, (int)b); ++my_q; }
-				if (b > 3 || y.x2 < min_intv) {
-					if (!kept && (nm == 0 || i + 1 < last_start)) {
-						uint64_t ax, t2 = emit_smem(A, r, kind, p, i + 1, pend, ax);
-						if (t2 != FTASK_NONE) push_ftask(A, t2, ax);
-						++nm; last_start = i + 1;
-					}
-				} else if (!kept || y.x2 != last_kept) { lep[--w] = pack_lep(y, pend); kept = true; last_kept = y.x2; }
-			}
-			if (!kept) break;
-			lo = w;
-		}
-		if (kind == TK_ROUND1) { uint64_t t2 = chain_round1(A, r, bt.ret, bt.x); if (t2 != FTASK_NONE) push_ftask(A, t2); }
-	}
 	atomicAdd(A.n_queries, my_q);
 }
 
