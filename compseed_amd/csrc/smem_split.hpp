@@ -1195,8 +1195,10 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 			}
 			if (!jumped) { ik = set_intv(ix, (int)A.seq[rb + (uint64_t)x]); i = x + 1; }
 			int nx = len;
+			BaseReader<1> rd;          // 8 read bases per load, the next 8 prefetched: in repeats a seed is a chain of dozens of steps
+			rd.start(A.seq, rb, i);
 			for (; i < len; ++i) {
-				const uint32_t b = A.seq[rb + (uint64_t)i];
+				const uint32_t b = rd.at(i);
 				if (b > 3) { nx = i + 1; break; }
 				const Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
 				if (y.x2 < A.max_mem_intv && i - x >= A.min_seed_len) { if (y.x2 > 0) emit_mem(A, (uint32_t)r, y, (uint32_t)x, (uint32_t)(i + 1)); nx = i + 1; break; }
