@@ -703,7 +703,7 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
 				}
 			}
-			{
+			if ((clk & 3) == 0) { // (every fourth step is enough: a lane that could have stopped earlier only repeats a few extensions)
 				const bool surv = step && walking;
 				const uint64_t lm = __ballot(surv) & gmask;
 				const uint64_t above = lane == 63 ? 0ull : lm & ~((2ull << lane) - 1ull);
@@ -722,8 +722,10 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 				active = false; valid = false;
 			}
 		}
-		wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
-		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
+		if (__ballot((push0 & push1) != FTASK_NONE)) { // (a call ends once in ~20 iterations: keep the dispenser code off the common path)
+			wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
+			wave_push<32>(O, push1 != FTASK_NONE, push1, A);
+		}
 	}
 }
 
