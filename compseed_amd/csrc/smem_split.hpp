@@ -1115,6 +1115,29 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const ui
 // where that does not apply (the seed would leave the SMEM, 20 or more occurrences, repeats without a unique SMEM) the
 // seed is computed on the FM index as before (jump table + extensions).  Same seeds, a fraction of the index reads:
 // on the bench workload round 3 was the largest single consumer of HBM traffic.
+// Length of the round-3 seed that starts at text position p: the smallest L >= k1 for which the L-mer at p has fewer than
+// max_intv occurrences (bwt.c:370).  The suffixes that share a prefix with suffix p sit around row ISA[p]; going outwards,
+// the running minimum of lcp[] on each side is the length shared with the j-th neighbour, non-increasing.  The L-mer has
+// 1 + #{neighbours sharing >= L} occurrences, so L = 1 + the (max_intv - 1)-th largest shared length (or k1 if fewer than
+// that many neighbours share k1 bases).  At most max_intv - 1 bytes of lcp[] on either side: two cache lines instead of the
+// dozens of bwt_extend calls such a seed costs in a repeat.  False when a capped value (255) would decide.
+__device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int k1, uint32_t max_intv, int &L)
+{
+	if (max_intv < 2 || max_intv > 41) return false;
+	const uint32_t m = max_intv - 1;
+	uint64_t up = isa_direct(ix, p), dn = up + 1;
+	uint32_t mu = ix.lcp[up], md = ix.lcp[dn], val = 0;
+	for (uint32_t t = 0; t < m; ++t) {
+		val = mu > md ? mu : md;
+		if (val < (uint32_t)k1) { L = k1; return true; }   // fewer than max_intv occurrences already at k1 bases
+		if (mu >= md) { --up; const uint32_t c = ix.lcp[up]; mu = c < mu ? c : mu; }
+		else { ++dn; const uint32_t c = ix.lcp[dn]; md = c < md ? c : md; }
+	}
+	if (val >= 255u) return false;                          // the true shared length is not known
+	L = (int)val + 1;
+	return true;
+}
+
 // cnt_snap: the per-read mem counts at a moment when every entry below them was complete (a copy taken between launches):
 // the kernel may run beside the last, thin iterations of rounds 1/2, which keep appending to the same lists.  A read that is
 // still being worked on simply finds fewer covering mems and takes more of its seeds from the index.
@@ -1180,11 +1203,13 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 				const uint32_t v = ix.rep[p];
 				Intv iv = {0, 0, 0}; bool ok = false;
 				if (v < (uint32_t)k1) { iv.x0 = isa_direct(ix, p); iv.x1 = isa_direct(ix, ix.seq_len - (p + (uint64_t)k1)); iv.x2 = 1; ok = true; }
-				else if (v < 255u && k1 < 255) ok = text_interval(ix, p, (uint32_t)k1, iv) && iv.x2 < A.max_mem_intv;
+				int L = k1;
+				if (!ok && k1 < 255 && r3_text_len(ix, p, k1, (uint32_t)(A.max_mem_intv > 0xffffffffull ? 0xffffffffull : A.max_mem_intv), L) && x + L <= ce)
+					ok = text_interval(ix, p, (uint32_t)L, iv) && iv.x2 < A.max_mem_intv;
 				if (ok) {
-					emit_mem(A, (uint32_t)r, iv, (uint32_t)x, (uint32_t)(x + k1));
-					my_q += (unsigned)(k1 - 1); my_hits += (unsigned)(k1 - 1); ++my_text;
-					x += k1;
+					emit_mem(A, (uint32_t)r, iv, (uint32_t)x, (uint32_t)(x + L));
+					my_q += (unsigned)(L - 1); my_hits += (unsigned)(L - 1); ++my_text;
+					x += L;
 					continue;
 				}
 			}
