@@ -1026,9 +1026,8 @@ struct RepReader { // rep[] bytes around a moving text position, one aligned 8-b
 	}
 };
 // bi-interval of the repeated substring of length v at text position pos (v <= 254, so the capped lcp[] decides exactly)
-__device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out)
+__device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out, int MAX_WALK = 48)
 {
-	constexpr int MAX_WALK = 48;
 	uint64_t lo = isa_direct(ix, pos), hi = lo, lo2 = isa_direct(ix, ix.seq_len - (pos + v));
 	int steps = 0;
 	while (ix.lcp[lo] >= v) { --lo; if (++steps > MAX_WALK) return false; }
@@ -1042,27 +1041,37 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 	const DevIndex &ix = A.ix;
 	const int len = end - beg, po = pivot - beg, k = A.min_seed_len;
 	if (k < 2 || po > 4096) return false;
+	// Where the SMEM touches an end of the READ the sweep cannot run past it either (bwt.c:303 stops the forward pass at
+	// the last base, bwt.c:326 the backward sweep in front of the first), so there the text still tells everything: ends
+	// are clipped to the read end, and a match that is still alive at the first base is reported there.
+	const bool at_start = beg == 0, at_end = (uint64_t)end == A.off[r + 1] - A.off[r];
 	const uint64_t P = sa_direct(ix, x0); // text position of read base `beg`
 	RepReader R = {ix.rep, ~0ull, 0};
-	int ne = 0, o0 = 0, v0 = 0, o1 = 0, v1 = 0; // at most two reported substrings; more: leave it to the index
-	int o = po, v = (int)R.at(P + (uint64_t)o);
+	constexpr int MAXC = 8;               // reported substrings per call; more (tandem arrays): leave it to the index
+	int co[MAXC], cv[MAXC], ne = 0;
+	auto eff = [&](int o, int &v) -> bool { // repeat length at offset o as far as it matters; false: the text cannot tell
+		v = (int)R.at(P + (uint64_t)o);
+		if (v == 0) return false;
+		if (o + v >= len) { if (!at_end) return false; v = len - o; return true; } // (a capped 255 that reaches the end is as good as the true value)
+		return v != 255;
+	};
+	int o = po, v = 0;
+	if (!eff(o, v)) return false;
 	for (;;) {
-		if (v == 255 || v == 0 || o + v >= len) return false; // capped / degenerate / reaches the end of the SMEM
 		if (o + v <= po) break;                               // no longer through the pivot: the sweep is over
-		if (o == 0) return false;                             // still through the pivot at the SMEM's start: may extend beyond it
-		int vp = (int)R.at(P + (uint64_t)o - 1);
-		if (vp == 255) return false;
-		if (vp <= v && v >= k) {
-			if (ne == 0) { o0 = o; v0 = v; } else if (ne == 1) { o1 = o; v1 = v; } else return false;
-			++ne;
+		if (o == 0) {                                         // alive at the SMEM's first base
+			if (!at_start) return false;                      // ... which is not the read's: the match may extend beyond it
+			if (v >= k) { if (ne == MAXC) return false; co[ne] = 0; cv[ne] = v; ++ne; }
+			break;
 		}
+		int vp = 0;
+		if (!eff(o - 1, vp)) return false;
+		if (vp <= v && v >= k) { if (ne == MAXC) return false; co[ne] = o; cv[ne] = v; ++ne; }
 		--o; v = vp;
 	}
-	Intv i0 = {0, 0, 0}, i1 = {0, 0, 0};
-	if (ne > 0 && !text_interval(ix, P + (uint64_t)o0, (uint32_t)v0, i0)) return false;
-	if (ne > 1 && !text_interval(ix, P + (uint64_t)o1, (uint32_t)v1, i1)) return false;
-	if (ne > 0) emit_mem(A, r, i0, (uint32_t)(beg + o0), (uint32_t)(beg + o0 + v0));
-	if (ne > 1) emit_mem(A, r, i1, (uint32_t)(beg + o1), (uint32_t)(beg + o1 + v1));
+	Intv ci[MAXC];
+	for (int j = 0; j < ne; ++j) if (!text_interval(ix, P + (uint64_t)co[j], (uint32_t)cv[j], ci[j], 192)) return false;
+	for (int j = 0; j < ne; ++j) emit_mem(A, r, ci[j], (uint32_t)(beg + co[j]), (uint32_t)(beg + co[j] + cv[j]));
 	return true;
 }
 // One lane per slot of the next forward queue.  Calls that are answered drop out; everything else is copied, without the
