@@ -584,6 +584,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
 		return CS_OK;
 	};
+	const bool fwd0_on = par->sst_mode != 0 && e->ix.text2 && A.jump && A.jump_k >= 8 && !(getenv("CS_FWD0") && atoi(getenv("CS_FWD0")) == 0);
 	uint64_t n_f = (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
 		A.fq_next = nxt; A.aux_next = aux_nxt;
@@ -595,6 +596,11 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			const bool r3_only = false;
 			HIP_TRY(hipMemsetAsync(e->d_bq.p, 0xff, cn * sizeof(BTask), s)); // slots without a call stay "no class"
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
+			if (iter == 0 && fwd0_on) { // the calls at the first base of each read: a kernel without LEPs, backward tasks, SST (smem_split.hpp)
+				unsigned g0 = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 8, (cn + 255) / 256);
+				hipLaunchKernelGGL((fwd0_kernel<256>), dim3(g0), dim3(256), 0, s, A, cur + c0);
+				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
+			}
 			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
 			HIP_TRY(hipGetLastError());
 			if (r3_async && !r3_launched && iter + 1 >= r3_after) { CS_TRY(launch_r3()); r3_launched = true; }

@@ -265,6 +265,32 @@ template <int DIR> struct BaseReader {
 	}
 };
 
+// The jk (<= 16) read bases from byte address a on, packed 2 bits each, first base most significant (as jump_fill_kernel
+// numbers k-mers), without a per-base loop: three aligned 8-byte words, funnelled into two, each word's eight 2-bit codes
+// squeezed together by three shift-or-mask steps, then the order of the 2-bit groups reversed.  bad > 3: an ambiguous base.
+__device__ __forceinline__ uint32_t kmer_code(const uint8_t *seq, uint64_t a, int jk, uint32_t &bad)
+{
+	const uint64_t a0 = a & ~7ull;
+	const uint64_t *w = reinterpret_cast<const uint64_t *>(seq + a0);
+	const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+	const uint32_t sh = (uint32_t)(a - a0) << 3;
+	uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+	uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
+	if (jk < 8) { lo &= (1ull << (8 * jk)) - 1ull; hi = 0; }
+	else if (jk < 16) hi &= (1ull << (8 * (jk - 8))) - 1ull;
+	bad = ((lo | hi) & 0xFCFCFCFCFCFCFCFCull) ? 4u : 0u;
+	auto squeeze = [](uint64_t v) -> uint32_t {
+		v &= 0x0303030303030303ull;
+		v = (v | (v >> 6)) & 0x000F000F000F000Full;
+		v = (v | (v >> 12)) & 0x000000FF000000FFull;
+		return (uint32_t)((v | (v >> 24)) & 0xFFFFull);
+	};
+	const uint32_t fwd = squeeze(lo) | squeeze(hi) << 16;        // base q at bits 2q
+	uint32_t rv = __brev(fwd);                                   // group q at 2(15-q), its two bits swapped
+	rv = ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
+	return rv >> (32 - 2 * jk);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // the call that follows a finished round-1 call at pivot x_cur: next pivot = end of the longest forward match, ambiguous
 // bases skipped.  A round-1 task carries, in the field that holds min_intv for round 2 (round 1 always uses 1), the
@@ -458,6 +484,91 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 }
 
 
+// The first launch of a batch: every call is a round-1 call at the read's first base, and almost all of them go jump table
+// -> a few extensions until the match is unique -> text mode -> one SMEM, the next pivot, a re-seeding candidate.  None of
+// that needs LEPs, backward tasks, the SST or round 3, so these calls get a kernel without them: half the registers of
+// fwd_kernel (the calls are latency-bound, so resident waves are what counts).  It takes the calls it can start from the
+// jump table and replaces them by no-ops in the queue; whatever is left (reads that begin with an ambiguous base, are
+// shorter than jump_k, or whose first jump_k-mer does not occur) is fwd_kernel's, launched over the same queue afterwards.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fwd0_kernel(const SplitArgs A, uint64_t *fq)
+{
+	const DevIndex &ix = A.ix;
+	const int jk = A.jump_k;
+	bool active = false, textm = false;
+	uint32_t r = 0, tw = 0;
+	int len = 0, i = 0;
+	Intv ik = {0, 0, 0};
+	BaseReader<1> rd;
+	uint32_t my_q = 0, my_hits = 0;
+	WavePool P = {0, 0, false};
+	WaveOut O = {0, 0};
+	for (;;) {
+		uint64_t t_id = 0;
+		bool got = pool_take<256>(P, !active, A.task_ctr, A.n_f, t_id);
+		if (!active && got) {
+			const uint64_t t = fq[t_id];
+			r = (uint32_t)t;
+			if ((uint32_t)(t >> 62) == TK_ROUND1 && ((t >> 32) & 0xffffu) == 0 && (int64_t)r < A.n_reads) {
+				const uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
+				if (len >= jk) {
+					uint32_t bad; const uint32_t code = kmer_code(A.seq, rb, jk, bad);
+					uint32_t e; unpack_lep(A.jump[code], ik, e);
+					if (bad <= 3 && ik.x2 > 0) {
+						fq[t_id] = FTASK_NONE;                       // ours
+						i = jk; textm = false; active = true;
+						my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
+						rd.start(A.seq, rb, i);
+					}
+				}
+			}
+		}
+		if (P.exhausted && __ballot(active) == 0) break; // wave-uniform exit
+		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
+		if (active) {
+			bool fin = false;
+			if (textm) { // as in fwd_kernel: the unique match against the 2-bit text, cursor in ik.x1
+				uint64_t tpos = ik.x1;
+				for (int q = 0; q < 8; ++q) {
+					uint32_t b = i < len ? rd.at(i) : 4u;
+					if (b > 3) { fin = true; break; }
+					++my_q; ++my_hits;
+					uint32_t tb = tpos < ix.seq_len ? (tw >> ((uint32_t)(tpos & 15) << 1)) & 3u : 4u;
+					if (tb != b) { fin = true; break; }
+					++i; ++tpos;
+					if ((tpos & 15) == 0) tw = ix.text2[tpos >> 4];
+				}
+				ik.x1 = tpos;
+				if (fin) ik.x1 = isa_direct(ix, ix.seq_len - tpos);
+			} else {
+				uint32_t b = i < len ? rd.at(i) : 4u;
+				if (b > 3) fin = true;
+				else {
+					++my_q;
+					const Intv y = extend1<false>(ix, ik, 3 - (int)b);
+					if (y.x2 == 0) fin = true;                       // bwt.c:313-315 with min_intv = 1
+					else {
+						ik = y; ++i;
+						if (ik.x2 == 1) { textm = true; ik.x1 = sa_direct(ix, ik.x0) + (uint64_t)i; tw = ix.text2[ik.x1 >> 4]; }
+					}
+				}
+			}
+			if (fin) { // the call's only SMEM is its longest forward match (bwt.c:325 starts the sweep at -1)
+				push0 = emit_smem(A, r, TK_ROUND1, ik, 0, (uint32_t)i, aux0);
+				push1 = chain_round1(A, r, i, 0);
+				active = false;
+			}
+		}
+		if (__ballot((push0 & push1) != FTASK_NONE)) {
+			wave_push<64>(O, push0 != FTASK_NONE, push0, A, aux0);
+			wave_push<64>(O, push1 != FTASK_NONE, push1, A);
+		}
+	}
+	wave_push_finish(O, A);
+	atomicAdd(A.n_queries, (unsigned long long)my_q);
+	if (my_hits) atomicAdd(A.n_sst_hits, (unsigned long long)my_hits);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
@@ -599,28 +710,8 @@ __device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, u
 	const int k = A.min_seed_len, jk = A.jump_k;
 	const int te = x + 1 + (int)gl;
 	if ((int)gl >= k - 1 || te > ret || te - k < 0) return false;
-	// the jump_k (<= 16) bases [te - jk, te) out of three aligned 8-byte words of the read, packed 2 bits each without a
-	// per-base loop: funnel the bytes into two words, squeeze each word's eight 2-bit codes together (three shift-or-mask
-	// steps), then reverse the order of the 2-bit groups (first base most significant, as jump_fill_kernel numbers k-mers)
-	const uint64_t a = rb + (uint64_t)(te - jk), a0 = a & ~7ull;
-	const uint64_t *w = reinterpret_cast<const uint64_t *>(A.seq + a0);
-	const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
-	const uint32_t sh = (uint32_t)(a - a0) << 3;
-	uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
-	uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
-	if (jk < 8) { lo &= (1ull << (8 * jk)) - 1ull; hi = 0; }
-	else if (jk < 16) hi &= (1ull << (8 * (jk - 8))) - 1ull;
-	const uint32_t bad = ((lo | hi) & 0xFCFCFCFCFCFCFCFCull) ? 4u : 0u;
-	auto squeeze = [](uint64_t v) -> uint32_t {
-		v &= 0x0303030303030303ull;
-		v = (v | (v >> 6)) & 0x000F000F000F000Full;
-		v = (v | (v >> 12)) & 0x000000FF000000FFull;
-		return (uint32_t)((v | (v >> 24)) & 0xFFFFull);
-	};
-	uint32_t fwd = squeeze(lo) | squeeze(hi) << 16;            // base q at bits 2q
-	uint32_t rv = __brev(fwd);                                   // group q at 2(15-q), its two bits swapped
-	rv = ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
-	const uint32_t code = rv >> (32 - 2 * jk);
+	uint32_t bad;
+	const uint32_t code = kmer_code(A.seq, rb + (uint64_t)(te - jk), jk, bad);
 	if (bad > 3) return false; // an ambiguous base inside the window: this end cannot reach min_seed_len
 	uint32_t dummy; unpack_lep(A.jump[code], e, dummy);
 	my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
