@@ -12,7 +12,7 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"][:60]
-        if any(x in k for x in ("smem_kernel", "sal_walk", "fwd_kernel", "bwd_all", "bwd_win", "r2text", "r3text", "sort_compact", "sal_gather")):
+        if any(x in k for x in ("smem_kernel", "sal_walk", "fwd_kernel", "fwd0_kernel", "bwd_all", "bwd_win", "r2text", "r3text", "sort_compact", "sal_gather")):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[(k, r["Counter_Name"])] += 1
     for k, d in agg.items():

@@ -21,7 +21,7 @@ with open(os.path.join(R, "gpurun_out", tag + "_kernel_stats.csv"), "w", newline
 import json
 f = glob.glob("/tmp/prof_%s/**/*kernel_trace.csv" % tag, recursive=True)[0]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))
-      if any(k in r["Kernel_Name"] for k in ("fwd_kernel", "bwd_all_kernel", "bwd_wide_kernel", "bwd_win", "r2text_kernel", "r3text_kernel", "init_tasks_kernel"))]
+      if any(k in r["Kernel_Name"] for k in ("fwd_kernel", "fwd0_kernel", "bwd_all_kernel", "bwd_wide_kernel", "bwd_win", "r2text_kernel", "r3text_kernel", "init_tasks_kernel"))]
 ev.sort()
 passes, cur, launches = [], None, []
 for s0, e0, name in ev:
@@ -46,9 +46,9 @@ agg = collections.defaultdict(float); n = collections.Counter(); per = []
 for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % tag, recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if r["Counter_Name"] == "FETCH_SIZE" and any(t in k for t in ("fwd_kernel", "bwd_", "r2text", "r3text", "sal_", "sort_compact")):
+        if r["Counter_Name"] == "FETCH_SIZE" and any(t in k for t in ("fwd_kernel", "fwd0_kernel", "bwd_", "r2text", "r3text", "sal_", "sort_compact")):
             per.append([int(r.get("Dispatch_Id", 0)), k.split("(")[0].split("::")[-1][:18], round(float(r["Counter_Value"]) / 1048576, 3)])
-        name = "fwd_kernel" if "fwd_kernel" in k else "bwd_win0_kernel" if "bwd_win0" in k else "bwd_win_kernel" if "bwd_win" in k else "r2text_kernel" if "r2text" in k else "r3text_kernel" if "r3text" in k else "bwd_all_kernel" if "bwd_all" in k else "bwd_wide_kernel" if "bwd_wide" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
+        name = "fwd0_kernel" if "fwd0_kernel" in k else "fwd_kernel" if "fwd_kernel" in k else "bwd_win0_kernel" if "bwd_win0" in k else "bwd_win_kernel" if "bwd_win" in k else "r2text_kernel" if "r2text" in k else "r3text_kernel" if "r3text" in k else "bwd_all_kernel" if "bwd_all" in k else "bwd_wide_kernel" if "bwd_wide" in k else "smem_kernel" if "smem_kernel" in k else "sal_gather" if "sal_gather" in k else None
         if name and r["Counter_Name"] == "FETCH_SIZE":
             agg[name] += float(r["Counter_Value"]); n[name] += 1
 out = {k: {"FETCH_SIZE_KiB_sum": v, "dispatches": n[k]} for k, v in agg.items()}
