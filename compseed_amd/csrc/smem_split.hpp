@@ -449,9 +449,8 @@ __global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
 					if (!fin) {
 						ik = y; ++i;
 						if (text_on && ik.x2 == 1 && kind == TK_ROUND1) { // unique from here on: continue on the text
-							kind = TK_TEXT;
-							ik.x1 = sa_direct(ix, ik.x0) + (uint64_t)(i - x);  // text cursor: the base that has to equal read base i
-							tw = ix.text2[ik.x1 >> 4];
+							const uint64_t tp = sa_direct(ix, ik.x0) + (uint64_t)(i - x); // text cursor: the base that has to equal read base i
+							if (tp <= ix.seq_len) { kind = TK_TEXT; ik.x1 = tp; tw = ix.text2[tp >> 4]; }  // (always: the match lies inside the text)
 						}
 					}
 				}
@@ -549,7 +548,10 @@ __global__ __launch_bounds__(BLOCK) void fwd0_kernel(const SplitArgs A, uint64_t
 					if (y.x2 == 0) fin = true;                       // bwt.c:313-315 with min_intv = 1
 					else {
 						ik = y; ++i;
-						if (ik.x2 == 1) { textm = true; ik.x1 = sa_direct(ix, ik.x0) + (uint64_t)i; tw = ix.text2[ik.x1 >> 4]; }
+						if (ik.x2 == 1) {
+							const uint64_t tp = sa_direct(ix, ik.x0) + (uint64_t)i;
+							if (tp <= ix.seq_len) { textm = true; ik.x1 = tp; tw = ix.text2[tp >> 4]; } // (always: the match lies inside the text)
+						}
 					}
 				}
 			}
@@ -1119,11 +1121,12 @@ struct RepReader { // rep[] bytes around a moving text position, one aligned 8-b
 // bi-interval of the repeated substring of length v at text position pos (v <= 254, so the capped lcp[] decides exactly)
 __device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out, int MAX_WALK = 48)
 {
+	if (v == 0 || pos + v > ix.seq_len) return false; // (cannot happen for a substring of a mem; a walk must never leave the arrays)
 	uint64_t lo = isa_direct(ix, pos), hi = lo, lo2 = isa_direct(ix, ix.seq_len - (pos + v));
 	int steps = 0;
-	while (ix.lcp[lo] >= v) { --lo; if (++steps > MAX_WALK) return false; }
-	while (ix.lcp[hi + 1] >= v) { ++hi; if (++steps > MAX_WALK) return false; }
-	while (ix.lcp[lo2] >= v) { --lo2; if (++steps > 2 * MAX_WALK) return false; }
+	while (lo > 0 && ix.lcp[lo] >= v) { --lo; if (++steps > MAX_WALK) return false; }
+	while (hi < ix.seq_len && ix.lcp[hi + 1] >= v) { ++hi; if (++steps > MAX_WALK) return false; }
+	while (lo2 > 0 && ix.lcp[lo2] >= v) { --lo2; if (++steps > 2 * MAX_WALK) return false; }
 	out.x0 = lo; out.x1 = lo2; out.x2 = hi - lo + 1;
 	return true;
 }
@@ -1137,6 +1140,7 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 	// are clipped to the read end, and a match that is still alive at the first base is reported there.
 	const bool at_start = beg == 0, at_end = (uint64_t)end == A.off[r + 1] - A.off[r];
 	const uint64_t P = sa_direct(ix, x0); // text position of read base `beg`
+	if (P >= ix.seq_len || P + (uint64_t)len > ix.seq_len) return false; // (an SMEM lies inside the text)
 	RepReader R = {ix.rep, ~0ull, 0};
 	constexpr int MAXC = 8;               // reported substrings per call; more (tandem arrays): leave it to the index
 	int co[MAXC], cv[MAXC], ne = 0;
@@ -1225,13 +1229,14 @@ __device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int 
 {
 	if (max_intv < 2 || max_intv > 41) return false;
 	const uint32_t m = max_intv - 1;
+	if (p >= ix.seq_len) return false;
 	uint64_t up = isa_direct(ix, p), dn = up + 1;
 	uint32_t mu = ix.lcp[up], md = ix.lcp[dn], val = 0;
 	for (uint32_t t = 0; t < m; ++t) {
 		val = mu > md ? mu : md;
 		if (val < (uint32_t)k1) { L = k1; return true; }   // fewer than max_intv occurrences already at k1 bases
-		if (mu >= md) { --up; const uint32_t c = ix.lcp[up]; mu = c < mu ? c : mu; }
-		else { ++dn; const uint32_t c = ix.lcp[dn]; md = c < md ? c : md; }
+		if (mu >= md) { if (up == 0) return false; --up; const uint32_t c = ix.lcp[up]; mu = c < mu ? c : mu; }
+		else { if (dn > ix.seq_len) return false; ++dn; const uint32_t c = ix.lcp[dn]; md = c < md ? c : md; }
 	}
 	if (val >= 255u) return false;                          // the true shared length is not known
 	L = (int)val + 1;
@@ -1259,7 +1264,11 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 				cb = ce = 0;
 				for (uint32_t a = 0; a < nm0; ++a) {
 					const uint64_t info = mine[a].info; const int mb = (int)(info >> 32), me = (int)(uint32_t)info;
-					if (x >= mb && x + k1 <= me) { cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0); break; } // any occurrence will do
+					if (x >= mb && x + k1 <= me) { // any occurrence will do
+						cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0);
+						if (cp >= ix.seq_len || cp + (uint64_t)(me - mb) > ix.seq_len) cb = ce = 0; // (a mem lies inside the text)
+						break;
+					}
 				}
 			}
 			if (x >= cb && x + k1 <= ce && ix.rep) {
