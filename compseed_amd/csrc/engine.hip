@@ -91,6 +91,7 @@ struct cs_engine {
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
 	DevBuf<uint32_t> d_fsa32; DevBuf<uint64_t> d_fsa64; // full suffix array (one of the two)
 	DevBuf<uint32_t> d_text2, d_isa32; DevBuf<uint64_t> d_isa64; // text mode: 2-bit text + inverse suffix array
+	DevBuf<uint64_t> d_bloom; int bloom_k = 0; uint32_t bloom_bits = 0; // k-mer filter of the text for the min_seed_len in use (built on first use)
 	DevBuf<uint32_t> d_cnt_snap; DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
 	// inputs
 	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
@@ -182,6 +183,7 @@ extern "C" int cs_device_count(int *n)
 	return CS_OK;
 }
 
+static int build_kmer_filter(cs_engine *e, int k);
 static int engine_init(cs_engine *e, const cs_index_view_t *v)
 {
 	int ndev = 0;
@@ -347,6 +349,11 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 			e->jump_k = jk;
 		}
 	}
+	if (e->jump_k) { // the k-mer filter of the window lanes for the default min_seed_len (mem_opt_init: 19); other values on first use
+		cs_params_t dp; cs_params_default(&dp);
+		CS_TRY(build_kmer_filter(e, dp.min_seed_len));
+		if (verbose) { fprintf(stderr, "[cs_engine] k-mer filter: %s\n", e->bloom_k ? "on" : "off"); fflush(stderr); }
+	}
 	if (verbose) { fprintf(stderr, "[cs_engine] full suffix array: %s\n", ix.fsa32 ? "4-byte" : ix.fsa64 ? "8-byte" : "off"); fflush(stderr); }
 	if (const char *s = getenv("CS_LEP_LDS")) { int v = atoi(s); g_lep_lds = (v == 10 || v == 13) ? v : 20; }
 	if (const char *s = getenv("CS_MEM_CAP")) { int c = atoi(s); if (c >= 1 && c <= 4096) e->cap = (uint32_t)c; }
@@ -371,7 +378,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
@@ -507,6 +514,27 @@ static int add_event_ms(cs_engine *e, hipEvent_t a, hipEvent_t b, double *acc)
 }
 
 
+// k-mer filter of the text for the window lanes (smem_split.hpp, kmer_filter_*): ~22 bits per text position, one per engine,
+// rebuilt when a call uses another min_seed_len (0.3 s at hg19 scale)
+static int build_kmer_filter(cs_engine *e, int k)
+{
+	const char *bs = getenv("CS_KMER_FILTER");
+	if (!e->ix.text2 || k < 8 || k > 24 || (bs && atoi(bs) == 0)) return CS_OK;
+	if (e->bloom_k == k) return CS_OK;
+	uint32_t bits = 10; // 2^bits words: at least seq_len / 3 of them
+	while (bits < 34 && ((uint64_t)1 << bits) * 3 < e->ix.seq_len) ++bits;
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	e->bloom_k = 0;
+	if ((((size_t)8) << bits) + ((size_t)24 << 30) >= free_b + e->d_bloom.cap * 8) return CS_OK; // no room: the window lanes do without
+	CS_TRY(e->d_bloom.reserve((size_t)1 << bits));
+	HIP_TRY(hipMemsetAsync(e->d_bloom.p, 0, ((size_t)8) << bits, e->stream));
+	hipLaunchKernelGGL(kmer_filter_fill_kernel, dim3((unsigned)(e->n_cu * 32)), dim3(256), 0, e->stream, e->ix, k, e->d_bloom.p, bits);
+	HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
+	e->bloom_k = k; e->bloom_bits = bits;
+	return CS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ split SMEM path
 // Runs the three rounds for reads [0, nb) of d_off with fwd_kernel / bwd_kernel (smem_split.hpp).  On return d_cnt holds
 // the number of mems per read, d_out the first `cap` of each, d_ovfrec/*n_ovf the rest.  Returns 1 when a task queue
@@ -544,6 +572,11 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	{ // window scheme for the backward sweeps (smem_split.hpp, bwd_win_run): needs the jump table and jump_k <= min_seed_len <= jump_k + 4
 		const char *ws = getenv("CS_WINDOW");
 		A.win = (!ws || atoi(ws) != 0) && par->sst_mode != 0 && A.jump && A.jump_k <= A.min_seed_len && A.min_seed_len - 1 <= WIN_LANES ? 1 : 0;
+	}
+	A.bloom = nullptr; A.bloom_bits = 0;
+	if (A.win) { // k-mer filter for the window lanes: built at engine creation for -k 19, here for any other value on its first use
+		CS_TRY(build_kmer_filter(e, A.min_seed_len));
+		if (e->bloom_k == A.min_seed_len) { A.bloom = e->d_bloom.p; A.bloom_bits = e->bloom_bits; }
 	}
 
 	uint64_t *cur = e->d_fqA.p, *nxt = e->d_fqB.p;

@@ -58,6 +58,7 @@ struct SplitArgs {
 	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
 	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
 	unsigned long long *n_text_sweeps;                // backward sweeps answered from the text (fwd_kernel)
+	const uint64_t *bloom; uint32_t bloom_bits;       // k-mer filter of the text for k = min_seed_len (kmer_filter_*), or null
 	int32_t   win;                                    // window scheme for the backward sweeps (bwd_win_run) is on
 	int32_t   text_sweep;                             // that shortcut is enabled (CS_TEXT_SWEEP, default on)
 	unsigned long long *n_btasks;                     // backward calls created by this forward launch (0: the backward kernels return at once)
@@ -292,6 +293,51 @@ __device__ __forceinline__ uint32_t kmer_code(const uint8_t *seq, uint64_t a, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// A filter over ALL min_seed_len-mers of the text (both strands: the text holds both): 2^bloom_bits 64-bit words, two bits
+// per k-mer inside one word chosen by a hash.  "Both bits set" has ~1 % false positives, "not both" is exact: that k-mer
+// does not occur.  The window lanes of the backward kernels ask it before anything else -- a chance window exists with
+// probability 2 %, so 97 % of them end after one 8-byte read instead of a jump-table read and two to four extensions.
+// Codes are 2 bits per base, first base least significant (the order of the 2-bit text), k <= 32.
+__device__ __forceinline__ uint64_t kmer_hash(uint64_t code) { uint64_t h = code * 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
+__device__ __forceinline__ bool kmer_filter_has(const uint64_t *bloom, uint32_t bits, uint64_t code)
+{
+	const uint64_t h = kmer_hash(code);
+	const uint64_t w = bloom[h >> (64u - bits)];
+	return ((w >> (h & 63u)) & (w >> ((h >> 6) & 63u)) & 1ull) != 0;
+}
+__global__ void kmer_filter_fill_kernel(const DevIndex ix, int k, uint64_t *bloom, uint32_t bits)
+{
+	const uint64_t n = ix.seq_len >= (uint64_t)k ? ix.seq_len - (uint64_t)k + 1 : 0;
+	const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t h = kmer_hash(text_win(ix, p) & mask);
+		atomicOr((unsigned long long *)&bloom[h >> (64u - bits)], (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)));
+	}
+}
+// the k (<= 24) read bases from byte address a on as a filter code; bad > 3: an ambiguous base among them
+__device__ __forceinline__ uint64_t kmer_code_lsb(const uint8_t *seq, uint64_t a, int k, uint32_t &bad)
+{
+	const uint64_t a0 = a & ~7ull;
+	const uint64_t *w = reinterpret_cast<const uint64_t *>(seq + a0);
+	const uint64_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+	const uint32_t sh = (uint32_t)(a - a0) << 3;
+	uint64_t b0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;      // bases 0..7
+	uint64_t b1 = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;      // bases 8..15
+	uint64_t b2 = sh ? (w2 >> sh) | (w3 << (64u - sh)) : w2;      // bases 16..23
+	if (k < 24) b2 &= k > 16 ? ((1ull << (8 * (k - 16))) - 1ull) : 0ull;
+	if (k < 16) b1 &= k > 8 ? ((1ull << (8 * (k - 8))) - 1ull) : 0ull;
+	if (k < 8) b0 &= (1ull << (8 * k)) - 1ull;
+	bad = ((b0 | b1 | b2) & 0xFCFCFCFCFCFCFCFCull) ? 4u : 0u;
+	auto squeeze = [](uint64_t v) -> uint64_t {
+		v &= 0x0303030303030303ull;
+		v = (v | (v >> 6)) & 0x000F000F000F000Full;
+		v = (v | (v >> 12)) & 0x000000FF000000FFull;
+		return (v | (v >> 24)) & 0xFFFFull;
+	};
+	return squeeze(b0) | squeeze(b1) << 16 | squeeze(b2) << 32;
+}
+
 // the call that follows a finished round-1 call at pivot x_cur: next pivot = end of the longest forward match, ambiguous
 // bases skipped.  A round-1 task carries, in the field that holds min_intv for round 2 (round 1 always uses 1), the
 // distance to the previous pivot + 1 when the forward pass ended ON the new pivot (no ambiguous base in between): no
@@ -712,6 +758,11 @@ __device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, u
 	const int k = A.min_seed_len, jk = A.jump_k;
 	const int te = x + 1 + (int)gl;
 	if ((int)gl >= k - 1 || te > ret || te - k < 0) return false;
+	if (A.bloom) { // does the min_seed_len-mer [te - k, te) occur at all?
+		uint32_t badk;
+		const uint64_t ck = kmer_code_lsb(A.seq, rb + (uint64_t)(te - k), k, badk);
+		if (badk > 3 || !kmer_filter_has(A.bloom, A.bloom_bits, ck)) return false;
+	}
 	uint32_t bad;
 	const uint32_t code = kmer_code(A.seq, rb + (uint64_t)(te - jk), jk, bad);
 	if (bad > 3) return false; // an ambiguous base inside the window: this end cannot reach min_seed_len

@@ -294,6 +294,27 @@ def test_round3_from_the_text_is_transparent(monkeypatch):
     assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
 
 
+def test_kmer_filter_is_transparent(monkeypatch):
+    """CS_KMER_FILTER=0: the window lanes go straight to the jump table; default: they first ask a filter over all
+    min_seed_len-mers of the text whether their window occurs at all ("no" is exact).  Same mems, fewer index reads."""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    tot = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CS_KMER_FILTER", mode)
+        e = ca.Engine(ix, 0)
+        e.reset_stats()
+        for name, pname in _data.golden_runs():
+            z, kw = _data.load_golden(name, pname)
+            bases, off = _data.load_reads(name)
+            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+        tot[mode] = e.stats()
+        e.close()
+    ix.close()
+    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
+    assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
+
+
 def test_cli_dump_matches_golden(tmp_path):
     """the CompSeed-compatible command line: same flags, seed dump identical to the reference golden"""
     import subprocess
