@@ -53,6 +53,7 @@ for f in glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % tag, recursive=Tru
             agg[name] += float(r["Counter_Value"]); n[name] += 1
 out = {k: {"FETCH_SIZE_KiB_sum": v, "dispatches": n[k]} for k, v in agg.items()}
 per.sort()
+out["passes_in_this_run"] = max(1, n.get("r3text_kernel", 0) or n.get("fwd0_kernel", 0) or 1)  # bench.py --warmup 0 adds an untimed priming pass
 out["per_dispatch_id_kernel_GiB"] = per
 json.dump(out, open(os.path.join(R, "gpurun_out", tag + "_pmc_fetch.json"), "w"), indent=1)
 print(json.dumps(out))
