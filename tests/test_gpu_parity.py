@@ -315,6 +315,21 @@ def test_kmer_filter_is_transparent(monkeypatch):
     assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
 
 
+@pytest.mark.parametrize("jk", ["0", "13", "9"])
+def test_other_jump_table_sizes(monkeypatch, jk):
+    """CS_JUMP_K: no jump table at all (forward passes and round 3 start base by base, no window scheme), or a smaller one
+    (13-mers: six extensions from the table entry to min_seed_len; 9-mers: below the window scheme's range for -k 19)"""
+    import compseed_amd as ca
+    monkeypatch.setenv("CS_JUMP_K", jk)
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0)
+    for name, pname in _data.golden_runs():
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+    e.close(); ix.close()
+
+
 def test_cli_dump_matches_golden(tmp_path):
     """the CompSeed-compatible command line: same flags, seed dump identical to the reference golden"""
     import subprocess
