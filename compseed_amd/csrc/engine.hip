@@ -602,9 +602,9 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	};
 	bool r3_launched = false;
 	if (r3_async && r3_after <= 0) { CS_TRY(launch_r3()); r3_launched = true; }
-	// r3text_kernel runs on the second stream beside the late iterations (from the 4th on they carry < 3 % of the tasks but
+	// r3text_kernel runs on the second stream beside the late iterations (from the 5th on they carry < 2 % of the tasks but
 	// still cost a launch chain and a host round trip each); it works from a snapshot of the mem counts
-	const int r3t_iter = getenv("CS_R3_TEXT_ITER") ? atoi(getenv("CS_R3_TEXT_ITER")) : 3;
+	const int r3t_iter = getenv("CS_R3_TEXT_ITER") ? atoi(getenv("CS_R3_TEXT_ITER")) : 4; // measured: 2: 67.8, 3: 66.9, 4: 66.0, 5: 66.8, 6: 68.0 ms
 	bool r3t_launched = false;
 	if (r3_text) CS_TRY(e->d_cnt_snap.reserve((size_t)nb + 1));
 	auto launch_r3text = [&]() -> int {
