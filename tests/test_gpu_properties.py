@@ -151,6 +151,32 @@ def test_parameter_sweep_shortcuts_on_off_and_oracle(world, kw):
     assert np.array_equal(on.seeds[: int(on.seed_off[m])], want["seeds"])
 
 
+def test_long_reads_vs_oracle(world):
+    """40 reads of 5-30 kbp (1 % substitutions, a few Ns), far beyond the lengths the packed fields of the shortcuts were
+    sized on: every path has to fall back cleanly where a field would overflow; result identical to the oracle"""
+    ca, eng, g = world["ca"], world["eng"], world["g"]
+    rng = np.random.default_rng(99)
+    reads = []
+    for j in range(40):
+        ln = int(rng.integers(5000, 30000)); st = int(rng.integers(0, g.size - ln))
+        q = g[st: st + ln].copy()
+        if j & 1:
+            q = (3 - q[::-1]).astype(np.uint8)
+        mut = rng.random(ln) < 0.01
+        q[mut] = (q[mut] + rng.integers(1, 4, int(mut.sum()))).astype(np.uint8) % 4
+        q[rng.random(ln) < 0.0005] = 4
+        reads.append(q)
+    bases = np.frombuffer(b"ACGTN", np.uint8)[np.concatenate(reads)]
+    off = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.uint64)
+    got = eng.seed_batch(bases, off)
+    bw, sa = world["ix"].arrays()
+    v = world["ix"].view
+    o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
+    want = o.seed_batch(bases, off, mode=1, threads=8)
+    assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"])
+    assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
+
+
 def test_full_baseline_size_properties():
     """BASELINE configs[1] shape: hg19-size index, 10 M x 150 bp reads, defaults; cheap size-independent checks on device
     results without copying 5 GB back: counts, sortedness, filters, and a checksum that must not change between two runs."""
