@@ -1384,12 +1384,15 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 			int nx = len;
 			BaseReader<1> rd;          // 8 read bases per load, the next 8 prefetched: in repeats a seed is a chain of dozens of steps
 			rd.start(A.seq, rb, i);
+			bool dead = ik.x2 == 0; // an empty interval stays empty (bwt.c:369 keeps extending it): no more index reads, the
+			                        // reference still walks on to the first ambiguous base or to min_seed_len bases and reports nothing
 			for (; i < len; ++i) {
 				const uint32_t b = rd.at(i);
 				if (b > 3) { nx = i + 1; break; }
+				if (dead) { if (i - x >= A.min_seed_len) { nx = i + 1; break; } continue; }
 				const Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
 				if (y.x2 < A.max_mem_intv && i - x >= A.min_seed_len) { if (y.x2 > 0) emit_mem(A, (uint32_t)r, y, (uint32_t)x, (uint32_t)(i + 1)); nx = i + 1; break; }
-				ik = y;
+				ik = y; dead = y.x2 == 0;
 			}
 			x = nx;
 		}
