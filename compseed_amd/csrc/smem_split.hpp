@@ -351,7 +351,7 @@ __device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r,
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 5) void fwd_kernel(const SplitArgs A)
+__global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 {
 	const DevIndex &ix = A.ix;
 	bool active = false;
