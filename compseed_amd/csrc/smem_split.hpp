@@ -536,7 +536,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 // jump table and replaces them by no-ops in the queue; whatever is left (reads that begin with an ambiguous base, are
 // shorter than jump_k, or whose first jump_k-mer does not occur) is fwd_kernel's, launched over the same queue afterwards.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fwd0_kernel(const SplitArgs A, uint64_t *fq)
+__global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint64_t *fq)
 {
 	const DevIndex &ix = A.ix;
 	const int jk = A.jump_k;
