@@ -108,6 +108,7 @@ struct cs_engine {
 	DevBuf<uint64_t> d_fqA, d_fqB, d_fqR; DevBuf<uint4> d_sst2, d_jump; int jump_k = 0; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
 	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
 	int smem_mode = 1;          // 1 = split kernels (default), 0 = fused one-lane-per-read kernel (CS_SMEM_MODE=fused)
+	int occ_win = 5; // ... of bwd_win_kernel
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
 	size_t lep_arena_bytes = (size_t)32 << 30;
 	cs_stats_t st{};
@@ -241,6 +242,7 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		int nb = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fwd_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_fwd = std::min(nb, 8);
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_all_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_bwd = std::min(nb, 8);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_win_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_win = std::min(nb, 8);
 		(void)hipGetLastError();
 	}
 	if (const char *m = getenv("CS_SMEM_MODE")) e->smem_mode = strcmp(m, "fused") == 0 ? 0 : 1;
@@ -638,7 +640,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 			HIP_TRY(hipGetLastError());
 			if (r3_async && !r3_launched && iter + 1 >= r3_after) { CS_TRY(launch_r3()); r3_launched = true; }
 			if (!r3_only) { // one launch works through all four size classes of the chunk's backward sweeps
-				unsigned cap_blocks = (unsigned)(e->n_cu * e->occ_bwd);
+				unsigned cap_blocks = (unsigned)(e->n_cu * (A.win ? e->occ_win : e->occ_bwd));
 				const int win0_occ = 8; // (sharing the CUs between the two window kernels by grid size was measured: slower in every split)
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
 				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed

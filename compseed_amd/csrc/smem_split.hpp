@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 
 // window scheme: ctrs[0] / ctrs[1] are the slot counters of the classes with up to 14 / 46 stored LEPs
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 5) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
+__global__ __launch_bounds__(BLOCK, 6) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
 	if (*A.n_btasks == 0) return;
 	WaveOut O = {0, 0};
