@@ -5,8 +5,9 @@ so that tests, bench.py and Python callers can drive the same entry points a C/C
 seed_and_extend) would.  There is no CPU fallback: importing works anywhere, but creating an
 Engine without the built library or without a GPU raises.
 """
-from .binding import (CSError, Engine, Index, Params, Result, Stats, lib_path, load_library, build_library,  # noqa: F401
-                      INTV_DT, SEED_DT)
+from . import binding  # noqa: F401
+from .binding import (CSError, Engine, EngineOptions, Index, Params, Result, Stats, lib_path, load_library, build_library,  # noqa: F401
+                      disable_mask, INTV_DT, SEED_DT)
 
-__all__ = ["CSError", "Engine", "Index", "Params", "Result", "Stats", "lib_path", "load_library", "build_library",
-           "INTV_DT", "SEED_DT"]
+__all__ = ["CSError", "Engine", "EngineOptions", "Index", "Params", "Result", "Stats", "lib_path", "load_library", "build_library",
+           "disable_mask", "INTV_DT", "SEED_DT"]

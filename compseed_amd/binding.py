@@ -10,8 +10,9 @@ INTV_DT = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")
 SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])               # cs_seed_t
 
 # every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
-SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build", "cs_index_save",
-           "cs_device_count", "cs_engine_create", "cs_engine_destroy", "cs_engine_seed_batch",
+SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
+           "cs_index_build_flags", "cs_index_save",
+           "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync"]
@@ -31,10 +32,38 @@ class IndexView(C.Structure):
 class Params(C.Structure):
     """cs_params_t; defaults = mem_opt_init (mapping/comp_seed.cpp:26-58)."""
     _fields_ = [("min_seed_len", C.c_int32), ("split_factor", C.c_float), ("split_width", C.c_int32),
-                ("max_occ", C.c_int32), ("max_mem_intv", C.c_uint64), ("want_sal", C.c_int32), ("sst_mode", C.c_int32)]
+                ("max_occ", C.c_int32), ("max_mem_intv", C.c_uint64), ("want_sal", C.c_int32), ("sst_mode", C.c_int32),
+                ("disable", C.c_uint32)]
 
-    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=1):
-        super().__init__(k, r, s, c, y, want_sal, sst_mode)
+    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=1, disable=0):
+        super().__init__(k, r, s, c, y, want_sal, sst_mode, disable)
+
+
+# cs_params_t.disable bits (include/compseed_amd.h CS_DISABLE_*)
+DISABLE = dict(text_mode=0x01, r2_text=0x02, text_sweep=0x04, window=0x08, r3_text=0x10, kmer_filter=0x20, fwd0=0x40, persist=0x80)
+
+
+def disable_mask(*names):
+    m = 0
+    for n in names:
+        m |= DISABLE[n]
+    return m
+
+
+class EngineOptions(C.Structure):
+    """cs_engine_options_t; defaults come from cs_engine_options_default()."""
+    _fields_ = [("full_sa", C.c_int32), ("sa64", C.c_int32), ("text_mode", C.c_int32), ("text_arrays", C.c_int32),
+                ("jump_k", C.c_int32), ("kmer_filter", C.c_int32), ("fused", C.c_int32), ("mem_cap", C.c_int32),
+                ("lep_arena_mb", C.c_int64), ("max_raw_mb", C.c_int64), ("r3_text_iter", C.c_int32),
+                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        load_library().cs_engine_options_default(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_) or k == "reserved":
+                raise TypeError("unknown engine option %r" % k)
+            setattr(self, k, v)
 
 
 class CResult(C.Structure):
@@ -45,7 +74,7 @@ class CResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("bases", C.c_uint64), ("mems", C.c_uint64), ("seeds", C.c_uint64),
                 ("bwt_queries", C.c_uint64), ("bwt_calls", C.c_uint64), ("sal_queries", C.c_uint64),
-                ("sal_calls", C.c_uint64), ("overflow_reads", C.c_uint64), ("seed_kernel_ms", C.c_double),
+                ("sal_calls", C.c_uint64), ("overflow_mems", C.c_uint64), ("seed_kernel_ms", C.c_double),
                 ("sal_kernel_ms", C.c_double), ("total_ms", C.c_double), ("seed_kernel_launches", C.c_uint64),
                 ("overflow_kernel_ms", C.c_double), ("overflow_kernel_launches", C.c_uint64),
                 ("reseed_text_calls", C.c_uint64), ("reseed_index_calls", C.c_uint64), ("sweep_text_calls", C.c_uint64),
@@ -92,6 +121,10 @@ def load_library():
     L.cs_index_free.argtypes = [vp]
     L.cs_index_free.restype = None
     L.cs_index_build.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    L.cs_index_build_flags.argtypes = [vp, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.cs_engine_options_default.argtypes = [C.POINTER(EngineOptions)]
+    L.cs_engine_options_default.restype = None
+    L.cs_engine_create_opts.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(EngineOptions), C.POINTER(vp)]
     L.cs_index_save.argtypes = [vp, C.c_char_p]
     L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
     L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
@@ -158,13 +191,13 @@ class Index:
         return self
 
     @classmethod
-    def build(cls, fwd_nt4, device=0):
-        """Build the FM-index of a genome (forward strand, codes 0..3) on the GPU (cs_index_build)."""
+    def build(cls, fwd_nt4, device=0, force_64bit=False, verbose=False):
+        """Build the FM-index of a genome (forward strand, codes 0..3) on the GPU (cs_index_build_flags)."""
         self = cls()
         L = load_library()
         g = np.ascontiguousarray(fwd_nt4, dtype=np.uint8)
         h = C.c_void_p()
-        _check(L.cs_index_build(g.ctypes.data, g.size, int(device), C.byref(h)))
+        _check(L.cs_index_build_flags(g.ctypes.data, g.size, int(device), (1 if force_64bit else 0) | (2 if verbose else 0), C.byref(h)))
         self._handle = h
         _check(L.cs_index_view(h, C.byref(self.view)))
         return self
@@ -218,11 +251,14 @@ def _view(ptr, dt, n, copy=True):
 class Engine:
     """One GPU, one resident index (cs_engine_t)."""
 
-    def __init__(self, index, device=0):
+    def __init__(self, index, device=0, **options):
+        """options: fields of cs_engine_options_t (full_sa, sa64, text_mode, text_arrays, jump_k, kmer_filter, fused, mem_cap,
+        lep_arena_mb, max_raw_mb, r3_text_iter, count_sal_merged, verbose)"""
         self._L = load_library()
         self._h = C.c_void_p()
         self._index = index  # keep host arrays alive during upload
-        _check(self._L.cs_engine_create(C.byref(index.view), int(device), C.byref(self._h)))
+        self.options = EngineOptions(**options)
+        _check(self._L.cs_engine_create_opts(C.byref(index.view), int(device), C.byref(self.options), C.byref(self._h)))
         self.device = device
 
     def close(self):

@@ -65,7 +65,7 @@ static void usage()
 int main(int argc, char **argv)
 {
 	cs_params_t par; cs_params_default(&par);
-	int n_threads = 1, n_gpus = -1; long fixed_chunk = 0; const char *dump = nullptr;
+	int n_threads = 1, n_gpus = -1, verbose = 0; long fixed_chunk = 0; const char *dump = nullptr;
 	std::vector<const char *> pos;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -79,8 +79,9 @@ int main(int argc, char **argv)
 		else if (a == "-K") fixed_chunk = atol(need());
 		else if (a == "--gpus") n_gpus = atoi(need());
 		else if (a == "--no-sal") par.want_sal = 0;
+		else if (a == "-v") verbose = atoi(need()) >= 4 ? 1 : 0; // bwa's verbosity levels: 4 = debugging output
 		else if (a == "--dump-seeds") dump = need();
-		else if (a.size() == 2 && a[0] == '-' && strchr("wdDWmABOELUxRHovThI", a[1])) (void)need(); // flags with a value, other stages
+		else if (a.size() == 2 && a[0] == '-' && strchr("wdDWmABOELUxRHoThI", a[1])) (void)need(); // flags with a value, other stages
 		else if (a.size() == 2 && a[0] == '-' && strchr("SPpj5qaCVYM1", a[1])) {}                    // switches, other stages
 		else if (a[0] == '-' && a.size() > 1) { fprintf(stderr, "[E::main] unknown option %s\n", a.c_str()); usage(); return 1; }
 		else pos.push_back(argv[i]);
@@ -95,8 +96,11 @@ int main(int argc, char **argv)
 	if (cs_device_count(&ndev) || ndev < 1) { fprintf(stderr, "[E::main] no MI355X visible: %s\n", cs_last_error()); return 1; }
 	if (n_gpus < 1 || n_gpus > ndev) n_gpus = ndev;
 	std::vector<cs_engine_t *> eng((size_t)n_gpus, nullptr);
+	cs_engine_options_t eopt; cs_engine_options_default(&eopt);
+	eopt.count_sal_merged = 1; // "SA Lookup: ... calls, % merged" as CompSeed prints it (main.cpp:209-210)
+	eopt.verbose = verbose;
 	for (int g = 0; g < n_gpus; ++g)
-		if (cs_engine_create(&view, g, &eng[g])) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); return 1; }
+		if (cs_engine_create_opts(&view, g, &eopt, &eng[g])) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); return 1; }
 
 	FILE *fp = fopen(pos[1], "r");
 	if (!fp) { fprintf(stderr, "[E::main] fail to open file `%s'.\n", pos[1]); return 1; }

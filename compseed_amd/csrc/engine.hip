@@ -20,7 +20,7 @@
 
 using namespace csd;
 
-static int g_lep_lds = 20; // LEP entries per lane kept in LDS (CS_LEP_LDS = 20 | 13 | 10)
+static const int g_lep_lds = 20; // LEP entries per lane kept in LDS by the fused kernel (13 and 10 were measured: slower)
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 int cs_fail_(int code, const std::string &msg) { return fail(code, msg); }
@@ -43,7 +43,14 @@ extern "C" void cs_params_default(cs_params_t *p)
 {
 	if (!p) return;
 	p->min_seed_len = 19; p->split_factor = 1.5f; p->split_width = 10; p->max_occ = 500; p->max_mem_intv = 20;
-	p->want_sal = 1; p->sst_mode = 1;
+	p->want_sal = 1; p->sst_mode = 1; p->disable = 0;
+}
+extern "C" void cs_engine_options_default(cs_engine_options_t *o)
+{
+	if (!o) return;
+	memset(o, 0, sizeof *o);
+	o->full_sa = 1; o->sa64 = 0; o->text_mode = 1; o->text_arrays = 1; o->jump_k = 15; o->kmer_filter = 1; o->fused = 0;
+	o->mem_cap = 64; o->lep_arena_mb = 32768; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ grow-only buffers
@@ -84,6 +91,7 @@ template <typename T> struct PinBuf {
 struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
+	cs_engine_options_t opt{};
 	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; // stream2: the independent round-3 chains; stream3: wide sweeps
 	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr, ev_wc = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -106,7 +114,7 @@ struct cs_engine {
 	PinBuf<unsigned long long> h_ctr;
 	// split (forward / cooperative backward) SMEM path
 	DevBuf<uint64_t> d_fqA, d_fqB, d_fqR; DevBuf<uint4> d_sst2, d_jump; int jump_k = 0; DevBuf<BTask> d_bq; DevBuf<uint4> d_lep; DevBuf<OvfRec> d_ovfrec;
-	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
+	DevBuf<uint32_t> d_okey, d_oidx, d_okey2, d_oidx2; DevBuf<uint64_t> d_okey64, d_okey64b; DevBuf<unsigned long long> d_sctr; PinBuf<unsigned long long> h_sctr;
 	int smem_mode = 1;          // 1 = split kernels (default), 0 = fused one-lane-per-read kernel (CS_SMEM_MODE=fused)
 	int occ_win = 5; // ... of bwd_win_kernel
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
@@ -195,7 +203,11 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, e->device));
 	e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	const bool verbose = getenv("CS_VERBOSE") != nullptr;
+	const cs_engine_options_t &opt = e->opt;
+	const bool verbose = opt.verbose != 0;
+	if (opt.mem_cap < 1 || opt.mem_cap > 4096 || opt.lep_arena_mb < 1 || opt.max_raw_mb < 1 || (opt.jump_k != 0 && (opt.jump_k < 6 || opt.jump_k > 15)))
+		return fail(CS_EINVAL, "cs_engine_options_t: mem_cap 1..4096, lep_arena_mb >= 1, max_raw_mb >= 1, jump_k 0 or 6..15");
+	for (int r : opt.reserved) if (r) return fail(CS_EINVAL, "cs_engine_options_t.reserved must be 0");
 	if (verbose) { fprintf(stderr, "[cs_engine] creating engine on device %d, seq_len %llu\n", e->device, (unsigned long long)v->seq_len); fflush(stderr); }
 	HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 	for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
@@ -245,8 +257,10 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_win_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_win = std::min(nb, 8);
 		(void)hipGetLastError();
 	}
-	if (const char *m = getenv("CS_SMEM_MODE")) e->smem_mode = strcmp(m, "fused") == 0 ? 0 : 1;
-	if (const char *m = getenv("CS_LEP_ARENA_MB")) { long v = atol(m); if (v >= 1) e->lep_arena_bytes = (size_t)v << 20; }
+	e->smem_mode = opt.fused ? 0 : 1;
+	e->lep_arena_bytes = (size_t)opt.lep_arena_mb << 20;
+	e->cap = (uint32_t)opt.mem_cap;
+	e->max_raw_bytes = (size_t)opt.max_raw_mb << 20;
 	CS_TRY(e->d_ctr.reserve(8));
 	CS_TRY(e->h_ctr.reserve(8));
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 8 * sizeof(unsigned long long), e->stream));
@@ -262,12 +276,11 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	if (verbose) { fprintf(stderr, "[cs_engine] index uploaded and re-laid out\n"); fflush(stderr); }
 	// full suffix array in HBM (4 B/row below 2^32 rows, else 8 B/row): 50 GB for hg19 of the 288 GB on board
 	ix.fsa32 = nullptr; ix.fsa64 = nullptr;
-	const char *fs = getenv("CS_FULL_SA");
-	if (!fs || atoi(fs) != 0) {
+	if (opt.full_sa) {
 		uint64_t rows = v->seq_len + 1;
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		bool small = rows < 0xffffffffull && !getenv("CS_FSA64"); // CS_FSA64: force 8-byte entries (tests)
+		bool small = rows < 0xffffffffull && !opt.sa64; // sa64: 8-byte entries on a small index (tests of the hg19-scale instantiation)
 		size_t need = (size_t)rows * (small ? 4 : 8);
 		if (need + ((size_t)8 << 30) < free_b) {
 			unsigned grid = (unsigned)((v->n_sa + 255) / 256);
@@ -288,12 +301,11 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	// text mode (smem_split.hpp): the 2-bit text and the inverse suffix array, derived from the full suffix array
 	ix.text2 = nullptr; ix.isa32 = nullptr; ix.isa64 = nullptr;
 	{
-		const char *tm = getenv("CS_TEXT_MODE");
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 		uint64_t rows = v->seq_len + 1;
 		size_t need = (size_t)rows * (ix.fsa32 ? 4 : 8) + (size_t)v->seq_len + (size_t)v->seq_len / 4 + ((size_t)24 << 30);
-		if ((!tm || atoi(tm) != 0) && (ix.fsa32 || ix.fsa64) && need < free_b) {
+		if (opt.text_mode && (ix.fsa32 || ix.fsa64) && need < free_b) {
 			DevBuf<uint8_t> tbytes;
 			CS_TRY(tbytes.reserve((size_t)v->seq_len + 64));
 			CS_TRY(e->d_text2.reserve((size_t)((v->seq_len + 15) >> 4) + 16));
@@ -315,11 +327,10 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	// re-seeding from the text (smem_split.hpp, r2text_kernel): capped LCP array and repeat-length array, 1 byte per row each
 	ix.lcp = nullptr; ix.rep = nullptr;
 	{
-		const char *rt = getenv("CS_R2_TEXT");
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 		size_t need = (size_t)v->seq_len * 2 + ((size_t)24 << 30);
-		if ((!rt || atoi(rt) != 0) && ix.text2 && need < free_b) {
+		if (opt.text_arrays && ix.text2 && need < free_b) {
 			uint64_t rows = v->seq_len + 1;
 			CS_TRY(e->d_lcp.reserve((size_t)rows + 64)); CS_TRY(e->d_rep.reserve((size_t)rows + 64));
 			unsigned grid = (unsigned)std::min<uint64_t>((rows + 256) / 256, 1u << 22);
@@ -340,8 +351,7 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	}
 	// round-3 jump table (smem_split.hpp): every 15-mer, 17 GB (13: 1 GB, measured 2 % slower); CS_JUMP_K = 0 disables
 	{
-		int jk = 15;
-		if (const char *s = getenv("CS_JUMP_K")) jk = atoi(s);
+		const int jk = opt.jump_k;
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 		if (jk >= 6 && jk <= 15 && ((size_t)16 << (2 * jk)) + ((size_t)8 << 30) < free_b) {
@@ -357,18 +367,20 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		if (verbose) { fprintf(stderr, "[cs_engine] k-mer filter: %s\n", e->bloom_k ? "on" : "off"); fflush(stderr); }
 	}
 	if (verbose) { fprintf(stderr, "[cs_engine] full suffix array: %s\n", ix.fsa32 ? "4-byte" : ix.fsa64 ? "8-byte" : "off"); fflush(stderr); }
-	if (const char *s = getenv("CS_LEP_LDS")) { int v = atoi(s); g_lep_lds = (v == 10 || v == 13) ? v : 20; }
-	if (const char *s = getenv("CS_MEM_CAP")) { int c = atoi(s); if (c >= 1 && c <= 4096) e->cap = (uint32_t)c; }
-	if (const char *s = getenv("CS_MAX_RAW_MB")) { long m = atol(s); if (m >= 1) e->max_raw_bytes = (size_t)m << 20; }
 	return CS_OK;
 }
 
 extern "C" int cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out)
 {
+	return cs_engine_create_opts(index, device, nullptr, out);
+}
+extern "C" int cs_engine_create_opts(const cs_index_view_t *index, int device, const cs_engine_options_t *opts, cs_engine_t **out)
+{
 	if (!index || !out || !index->bwt || !index->sa) return fail(CS_EINVAL, "cs_engine_create: null argument");
 	*out = nullptr;
 	cs_engine *e = new cs_engine();
 	e->device = device;
+	if (opts) e->opt = *opts; else cs_engine_options_default(&e->opt);
 	int rc = engine_init(e, index);
 	if (rc != CS_OK) { std::string keep = g_err; cs_engine_destroy(e); g_err = keep; return rc; }
 	*out = e;
@@ -385,7 +397,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
 	e->d_fqA.release(); e->d_fqB.release(); e->d_fqR.release(); e->d_sst2.release(); e->d_jump.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
-	e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
+	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
 	if (e->ev_r3a) (void)hipEventDestroy(e->ev_r3a);
@@ -431,12 +443,13 @@ static int scan_u64(cs_engine *e, const uint64_t *cnt, uint64_t *off, size_t n)
 	return CS_OK;
 }
 
-__global__ void max_len_kernel(const uint64_t *off, int64_t n, unsigned long long *out_max, unsigned long long *bad)
+__global__ void max_len_kernel(const uint64_t *off, int64_t n, uint64_t n_bases, unsigned long long *out_max, unsigned long long *bad)
 {
 	unsigned long long len = 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (off[0] != 0 || off[n] != n_bases)) atomicAdd(bad, 1ull); // the reads must tile [0, n_bases)
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) { // few waves: few atomics
 		uint64_t a = off[r], b = off[r + 1];
-		if (b < a) atomicAdd(bad, 1ull); else if (b - a > len) len = b - a;
+		if (b < a || b > n_bases) atomicAdd(bad, 1ull); else if (b - a > len) len = b - a;
 	}
 	for (int o = 32; o > 0; o >>= 1) { unsigned long long other = __shfl_xor(len, o); len = other > len ? other : len; } // one atomic per wave
 	if ((threadIdx.x & 63) == 0) atomicMax(out_max, len);
@@ -468,6 +481,24 @@ __global__ void sort_compact_list_kernel(const OutMem *raw, const uint32_t *cnt2
 		for (uint32_t b = 0; b < n; ++b) { uint64_t kb = src[b].info; rank += (kb < ka) || (kb == ka && b < a); }
 		dst[rank] = src[a];
 	}
+}
+
+// SA slots as CompSeed merges them (comp_seed.cpp:2327-2334): identical slots inside one 512-read batch are looked up once.
+// key = batch << 37 | slot (slots < 2^37: checked at engine creation); sorted, then the distinct keys are counted.
+__global__ void sal_keys_kernel(const OutSeed *seeds, const uint64_t *seed_off, int64_t n_reads, uint64_t *keys)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+		const uint64_t hi = (uint64_t)(r >> 9) << 37; // BATCH_SIZE 512, comp_seed.h:36
+		for (uint64_t j = seed_off[r]; j < seed_off[r + 1]; ++j) keys[j] = hi | (uint64_t)seeds[j].rbeg;
+	}
+}
+__global__ void count_distinct_kernel(const uint64_t *keys, uint64_t n, unsigned long long *out)
+{
+	unsigned long long c = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+	if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)std::max<int64_t>(1, (n + block - 1) / block); }
@@ -520,8 +551,7 @@ static int add_event_ms(cs_engine *e, hipEvent_t a, hipEvent_t b, double *acc)
 // rebuilt when a call uses another min_seed_len (0.3 s at hg19 scale)
 static int build_kmer_filter(cs_engine *e, int k)
 {
-	const char *bs = getenv("CS_KMER_FILTER");
-	if (!e->ix.text2 || k < 8 || k > 24 || (bs && atoi(bs) == 0)) return CS_OK;
+	if (!e->ix.text2 || k < 8 || k > 24 || !e->opt.kmer_filter) return CS_OK;
 	if (e->bloom_k == k) return CS_OK;
 	uint32_t bits = 10; // 2^bits words: at least seq_len / 3 of them
 	while (bits < 34 && ((uint64_t)1 << bits) * 3 < e->ix.seq_len) ++bits;
@@ -541,9 +571,22 @@ static int build_kmer_filter(cs_engine *e, int k)
 // Runs the three rounds for reads [0, nb) of d_off with fwd_kernel / bwd_kernel (smem_split.hpp).  On return d_cnt holds
 // the number of mems per read, d_out the first `cap` of each, d_ovfrec/*n_ovf the rest.  Returns 1 when a task queue
 // overflowed (the caller then falls back to the fused kernel for this sub-batch).
+static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, int64_t nb, uint32_t max_len, uint64_t *n_ovf_out);
 static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, int64_t nb, uint32_t max_len, uint64_t *n_ovf_out)
 {
+	const int rc = run_smem_split_body(e, par, d_off, nb, max_len, n_ovf_out);
+	if (rc != CS_OK) { // every early exit: kernels on the side streams may still be appending to buffers the next call reuses
+		const std::string keep = g_err;
+		(void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4);
+		(void)hipGetLastError();
+		g_err = keep;
+	}
+	return rc;
+}
+static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, int64_t nb, uint32_t max_len, uint64_t *n_ovf_out)
+{
 	hipStream_t s = e->stream;
+	const uint32_t dis = par->sst_mode != 0 ? par->disable : ~0u; // sst_mode 0: the literal algorithm, every shortcut off
 	*n_ovf_out = 0;
 	if (par->split_width > 16382) return 1; // min_intv does not fit the 14-bit task field: use the fused kernel
 	const uint32_t stride = max_len + 1;
@@ -551,7 +594,8 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	uint64_t chunk = std::max<uint64_t>(4096, e->lep_arena_bytes / ((size_t)stride * sizeof(uint4)));
 	chunk = std::min<uint64_t>(chunk, fq_cap);
 	CS_TRY(e->d_fqA.reserve(fq_cap)); CS_TRY(e->d_fqB.reserve(fq_cap)); CS_TRY(e->d_fqR.reserve((size_t)nb + 1));
-	const bool r2text = e->ix.rep != nullptr && par->sst_mode != 0;
+	const bool have_arrays = e->ix.rep != nullptr && par->sst_mode != 0;
+	const bool r2text = have_arrays && !(dis & CS_DISABLE_R2_TEXT);
 	if (r2text) { CS_TRY(e->d_auxA.reserve(fq_cap)); CS_TRY(e->d_auxB.reserve(fq_cap)); }
 	CS_TRY(e->d_bq.reserve(chunk)); CS_TRY(e->d_lep.reserve(chunk * stride));
 	CS_TRY(e->d_ovfrec.reserve(ovf_cap));
@@ -561,6 +605,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 
 	SplitArgs A;
 	A.ix = e->ix; A.seq = e->d_seq.p; A.off = d_off; A.n_reads = nb;
+	if (dis & CS_DISABLE_TEXT_MODE) A.ix.text2 = nullptr;
 	A.out = e->d_out.p; A.out_cnt = e->d_cnt.p; A.cap = e->cap;
 	A.ovf = e->d_ovfrec.p; A.ovf_cnt = C + 6; A.ovf_cap = ovf_cap;
 	A.min_seed_len = par->min_seed_len;
@@ -570,13 +615,11 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	A.lep = e->d_lep.p; A.lep_stride = stride;
 	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p; A.jump = e->jump_k ? e->d_jump.p : nullptr; A.jump_k = e->jump_k;
 	A.fq_cap = fq_cap; A.n_f_next = C + 1; A.n_btasks = C + 13; A.n_text_sweeps = C + 14;
-	{ const char *ts = getenv("CS_TEXT_SWEEP"); A.text_sweep = (!ts || atoi(ts) != 0) ? 1 : 0; }
-	{ // window scheme for the backward sweeps (smem_split.hpp, bwd_win_run): needs the jump table and jump_k <= min_seed_len <= jump_k + 4
-		const char *ws = getenv("CS_WINDOW");
-		A.win = (!ws || atoi(ws) != 0) && par->sst_mode != 0 && A.jump && A.jump_k <= A.min_seed_len && A.min_seed_len - 1 <= WIN_LANES ? 1 : 0;
-	}
+	A.text_sweep = (dis & CS_DISABLE_TEXT_SWEEP) ? 0 : 1;
+	// window scheme for the backward sweeps (smem_split.hpp, bwd_win_run): needs the jump table and jump_k <= min_seed_len <= jump_k + 4
+	A.win = !(dis & CS_DISABLE_WINDOW) && par->sst_mode != 0 && A.jump && A.jump_k <= A.min_seed_len && A.min_seed_len - 1 <= WIN_LANES ? 1 : 0;
 	A.bloom = nullptr; A.bloom_bits = 0;
-	if (A.win) { // k-mer filter for the window lanes: built at engine creation for -k 19, here for any other value on its first use
+	if (A.win && !(dis & CS_DISABLE_KMER_FILTER)) { // k-mer filter for the window lanes: built at engine creation for -k 19, here for any other value on its first use
 		CS_TRY(build_kmer_filter(e, A.min_seed_len));
 		if (e->bloom_k == A.min_seed_len) { A.bloom = e->d_bloom.p; A.bloom_bits = e->bloom_bits; }
 	}
@@ -587,10 +630,11 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	HIP_TRY(hipEventRecord(e->ev[0], s));
 	hipLaunchKernelGGL(init_tasks_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, A, cur, e->d_fqR.p);
 	// Round 3 depends on nothing: it runs on a low-priority second stream and fills the tails of the launches below.
-	const int r3_text_env = getenv("CS_R3_TEXT") ? atoi(getenv("CS_R3_TEXT")) : 1;
-	const bool r3_text = A.max_mem_intv > 0 && r2text && r3_text_env != 0; // round 3 after rounds 1/2, mostly from the text (r3text_kernel)
+	// round 3 after rounds 1/2, mostly from the text (r3text_kernel).  Its text paths take "fewer than max_mem_intv occurrences" as
+	// "unique" and compare the 255-capped rep[] bytes with min_seed_len + 1, so -y 1 and -k >= 254 stay on the index (fwd_kernel)
+	const bool r3_text = have_arrays && !(dis & CS_DISABLE_R3_TEXT) && A.max_mem_intv >= 2 && A.min_seed_len + 1 <= 254;
 	bool r3_async = A.max_mem_intv > 0 && !r3_text;
-	const int r3_after = getenv("CS_R3_AFTER") ? atoi(getenv("CS_R3_AFTER")) : 0; // start round 3 after this many forward launches
+	const int r3_after = 0; // forward launches before round 3 starts on the index (measured: at once is best)
 	auto launch_r3 = [&]() -> int {
 		SplitArgs R = A;
 		R.fq = e->d_fqR.p; R.n_f = (uint64_t)nb; R.task_ctr = C + 10;
@@ -606,7 +650,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	if (r3_async && r3_after <= 0) { CS_TRY(launch_r3()); r3_launched = true; }
 	// r3text_kernel runs on the second stream beside the late iterations (from the 5th on they carry < 2 % of the tasks but
 	// still cost a launch chain and a host round trip each); it works from a snapshot of the mem counts
-	const int r3t_iter = getenv("CS_R3_TEXT_ITER") ? atoi(getenv("CS_R3_TEXT_ITER")) : 4; // measured: 2: 67.8, 3: 66.9, 4: 66.0, 5: 66.8, 6: 68.0 ms
+	const int r3t_iter = e->opt.r3_text_iter; // measured: 2: 67.8, 3: 66.9, 4: 66.0, 5: 66.8, 6: 68.0 ms
 	bool r3t_launched = false;
 	if (r3_text) CS_TRY(e->d_cnt_snap.reserve((size_t)nb + 1));
 	auto launch_r3text = [&]() -> int {
@@ -619,7 +663,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
 		return CS_OK;
 	};
-	const bool fwd0_on = par->sst_mode != 0 && e->ix.text2 && A.jump && A.jump_k >= 8 && !(getenv("CS_FWD0") && atoi(getenv("CS_FWD0")) == 0);
+	const bool fwd0_on = par->sst_mode != 0 && A.ix.text2 && A.jump && A.jump_k >= 8 && !(dis & CS_DISABLE_FWD0);
 	uint64_t n_f = (uint64_t)nb;
 	for (int iter = 0; n_f > 0; ++iter) {
 		A.fq_next = nxt; A.aux_next = aux_nxt;
@@ -674,9 +718,9 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 		if (r3_text && !r3t_launched && iter + 1 >= r3t_iter) { CS_TRY(launch_r3text()); r3t_launched = true; }
 		HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
-		if (H[7]) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4); return 1; }
+		if (H[7]) return 1; // a queue or the overflow records ran full: the caller redoes the sub-batch with the fused kernel
 		n_f = r2text ? H[16] : H[1];
-		if (getenv("CS_VERBOSE")) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[11], H[12]);
+		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[11], H[12]);
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
 		if (!r2text) { std::swap(cur, nxt); std::swap(aux_cur, aux_nxt); } // (r2text_kernel has compacted the next queue into `cur`)
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
@@ -687,11 +731,12 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	HIP_TRY(hipEventRecord(e->ev[1], s));
 	HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
+	if (H[7]) return 1; // round 3 is joined only here: it may have run the overflow records full after the last check in the loop
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 	e->st.seed_kernel_launches++;
 	e->st.bwt_queries += H[8]; e->st.bwt_calls += H[8] - H[9]; // calls = queries not answered by the on-device SST
 	e->st.reseed_text_calls += H[11]; e->st.reseed_index_calls += H[12]; e->st.sweep_text_calls += H[14]; e->st.r3_text_seeds += H[15];
-	*n_ovf_out = H[6];
+	*n_ovf_out = H[6]; // (<= ovf_cap: a record beyond it sets the error flag)
 	return CS_OK;
 }
 
@@ -712,10 +757,10 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	HIP_TRY(hipEventRecord(e->ev[2], s));
 	// read lengths: MAX_READ_LEN 65535 (comp_seed.h:39; the reference aborts at main.cpp:83-86)
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, 3 * sizeof(unsigned long long), s));
-	hipLaunchKernelGGL(max_len_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads, 256), (int64_t)e->n_cu * 8)), dim3(256), 0, s, d_off, n_reads, e->d_ctr.p + 3, e->d_ctr.p + 4);
+	hipLaunchKernelGGL(max_len_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads, 256), (int64_t)e->n_cu * 8)), dim3(256), 0, s, d_off, n_reads, n_bases, e->d_ctr.p + 3, e->d_ctr.p + 4);
 	HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
-	if (e->h_ctr.p[4]) return fail(CS_EINVAL, "offsets are not non-decreasing");
+	if (e->h_ctr.p[4]) return fail(CS_EINVAL, "offsets must start at 0, be non-decreasing and end at n_bases");
 	uint32_t max_len = (uint32_t)e->h_ctr.p[3];
 	if (e->h_ctr.p[3] >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
 
@@ -744,7 +789,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 			if (rc < 0) return rc;
 			if (rc == 0) {
 				if (n_ovf2) { // the few mems beyond a read's first `cap`: sort their records by read id
-					e->st.overflow_reads += n_ovf2;
+					e->st.overflow_mems += n_ovf2;
 					CS_TRY(e->d_okey.reserve(n_ovf2)); CS_TRY(e->d_oidx.reserve(n_ovf2)); CS_TRY(e->d_okey2.reserve(n_ovf2)); CS_TRY(e->d_oidx2.reserve(n_ovf2));
 					hipLaunchKernelGGL(ovf_keys_kernel, dim3(grid_for((int64_t)n_ovf2, 256)), dim3(256), 0, s, e->d_ovfrec.p, n_ovf2, e->d_okey.p, e->d_oidx.p);
 					size_t tb = 0;
@@ -782,7 +827,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		int64_t n_ovf = (int64_t)e->h_ctr.p[2];
 		uint32_t cap2 = 0;
 		if (n_ovf > 0) { // second pass over the few reads with more than `cap` mems, capacity grown until everything fits
-			e->st.overflow_reads += (uint64_t)n_ovf;
+			e->st.overflow_mems += (uint64_t)n_ovf;
 			cap2 = std::max<uint32_t>(256, cap * 8);
 			for (;;) {
 				CS_TRY(e->d_out2.reserve((size_t)n_ovf * cap2));
@@ -846,19 +891,37 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		if (total_mems)
 			hipLaunchKernelGGL(sal_expand_kernel, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->d_mems.p, total_mems,
 			                   (uint32_t)par->max_occ, som.p, e->d_seeds.p);
+		hipLaunchKernelGGL(seed_off_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, e->d_mem_off.p, som.p, n_reads, e->d_seed_off.p);
+		uint64_t sal_calls = total_seeds;
+		if (e->opt.count_sal_merged && total_seeds) { // statistics option; the slots are still in rbeg here (the gather below overwrites them)
+			unsigned bits = 38;
+			while (bits < 64 && ((uint64_t)(n_reads >> 9) >> (bits - 37))) ++bits;
+			CS_TRY(e->d_okey64.reserve((size_t)total_seeds)); CS_TRY(e->d_okey64b.reserve((size_t)total_seeds));
+			hipLaunchKernelGGL(sal_keys_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads, 256), (int64_t)e->n_cu * 16)), dim3(256), 0, s,
+			                   (const OutSeed *)e->d_seeds.p, (const uint64_t *)e->d_seed_off.p, n_reads, e->d_okey64.p);
+			rocprim::double_buffer<uint64_t> kb(e->d_okey64.p, e->d_okey64b.p);
+			size_t tb = 0;
+			HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, kb, (size_t)total_seeds, 0u, bits, s));
+			CS_TRY(e->d_tmp2.reserve(tb + 16));
+			HIP_TRY(rocprim::radix_sort_keys((void *)e->d_tmp2.p, tb, kb, (size_t)total_seeds, 0u, bits, s));
+			HIP_TRY(hipMemsetAsync(e->d_ctr.p + 5, 0, sizeof(unsigned long long), s));
+			hipLaunchKernelGGL(count_distinct_kernel, dim3((unsigned)e->n_cu * 8), dim3(256), 0, s, (const uint64_t *)kb.current(), total_seeds, e->d_ctr.p + 5);
+			HIP_TRY(hipMemcpyAsync(e->h_ctr.p + 5, e->d_ctr.p + 5, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipStreamSynchronize(s));
+			sal_calls = e->h_ctr.p[5];
+		}
 		if (total_seeds) {
 			if (e->ix.fsa32 || e->ix.fsa64)
 				hipLaunchKernelGGL(sal_gather_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
 			else
 				hipLaunchKernelGGL(sal_walk_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
 		}
-		hipLaunchKernelGGL(seed_off_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, e->d_mem_off.p, som.p, n_reads, e->d_seed_off.p);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(e->ev[1], s));
 		HIP_TRY(hipStreamSynchronize(s));
 		CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.sal_kernel_ms));
 		*n_seeds_out = total_seeds;
-		e->st.sal_queries += total_seeds; e->st.sal_calls += total_seeds;
+		e->st.sal_queries += total_seeds; e->st.sal_calls += sal_calls;
 	}
 	HIP_TRY(hipEventRecord(e->ev[3], s));
 	HIP_TRY(hipStreamSynchronize(s));

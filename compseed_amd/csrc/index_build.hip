@@ -232,7 +232,7 @@ template <typename idx_t> __global__ void carry_max_kernel(idx_t *p) { if (p[-1]
 } // namespace
 
 template <typename idx_t>
-static int build_impl(const uint8_t *fwd_nt4, uint64_t l_pac, int device, cs_index_t **out)
+static int build_impl(const uint8_t *fwd_nt4, uint64_t l_pac, int device, bool verbose, cs_index_t **out)
 {
 	int rc = CS_OK;
 	const uint64_t n = 2 * l_pac, m = n + 1; // m rows including the $ row
@@ -311,7 +311,6 @@ static int build_impl(const uint8_t *fwd_nt4, uint64_t l_pac, int device, cs_ind
 		return hipSuccess;
 	};
 
-	const bool verbose = getenv("CS_VERBOSE") != nullptr;
 	auto stage = [&](const char *what) {
 		if (!verbose) return;
 		size_t fr = 0, to = 0; (void)hipMemGetInfo(&fr, &to);
@@ -458,13 +457,17 @@ done:
 
 extern "C" int cs_index_build(const uint8_t *fwd_nt4, uint64_t l_pac, int device, cs_index_t **out)
 {
+	return cs_index_build_flags(fwd_nt4, l_pac, device, 0u, out);
+}
+extern "C" int cs_index_build_flags(const uint8_t *fwd_nt4, uint64_t l_pac, int device, uint32_t flags, cs_index_t **out)
+{
 	if (!fwd_nt4 || !out || l_pac == 0) return cs_fail_(CS_EINVAL, "cs_index_build: bad argument");
 	*out = nullptr;
 	if (2 * l_pac + 1 >= (1ull << 33)) return cs_fail_(CS_ERANGE, "cs_index_build: genome longer than 2^32 bp");
 	for (uint64_t i = 0; i < l_pac; ++i) if (fwd_nt4[i] > 3) return cs_fail_(CS_EINVAL, "cs_index_build: base code > 3 (replace ambiguous bases first, bntseq.c:295)");
-	const char *force64 = getenv("CS_BUILD_64BIT"); // tests: run the 64-bit instantiation on a small genome
-	if (2 * l_pac + 1 < 0xffffffffull && !(force64 && atoi(force64))) return build_impl<uint32_t>(fwd_nt4, l_pac, device, out);
-	return build_impl<uint64_t>(fwd_nt4, l_pac, device, out);
+	const bool verbose = (flags & CS_BUILD_VERBOSE) != 0;
+	if (2 * l_pac + 1 < 0xffffffffull && !(flags & CS_BUILD_FORCE_64BIT)) return build_impl<uint32_t>(fwd_nt4, l_pac, device, verbose, out);
+	return build_impl<uint64_t>(fwd_nt4, l_pac, device, verbose, out);
 }
 
 // write <prefix>.bwt and <prefix>.sa in the reference's formats (bwt_dump_bwt / bwt_dump_sa, FM_index/bwt.c:385-407)

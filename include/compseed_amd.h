@@ -61,7 +61,40 @@ typedef struct {
 	int32_t  want_sal;       /* 1: also produce seeds (SAL block), 0: mems only */
 	int32_t  sst_mode;       /* 1: on-device SST (LDS-resident memo of bwt_extend, mapping/SST.h) on [default], 0: off.
 	                          * Results are identical either way; only speed and the bwt_calls counter differ */
+	uint32_t disable;        /* bit mask of CS_DISABLE_*: switch single exact shortcuts off for this call (A/B parity tests,
+	                          * profiling).  0 [default] = everything the engine was created with is used */
 } cs_params_t;
+
+/* cs_params_t.disable: every mechanism below is exact; switching one off changes speed and counters only */
+#define CS_DISABLE_TEXT_MODE    0x01u  /* unique forward matches compared against the 2-bit text instead of the FM index      */
+#define CS_DISABLE_R2_TEXT      0x02u  /* re-seeding calls of unique SMEMs answered from rep[] / lcp[] / inverse SA           */
+#define CS_DISABLE_TEXT_SWEEP   0x04u  /* backward sweeps bounded by the previous pivot read off the text                     */
+#define CS_DISABLE_WINDOW       0x08u  /* window scheme for the backward sweeps (jump table + k-mer filter)                   */
+#define CS_DISABLE_R3_TEXT      0x10u  /* round-3 seeds inside a mem taken from the text arrays                               */
+#define CS_DISABLE_KMER_FILTER  0x20u  /* k-mer filter in front of the window lanes                                           */
+#define CS_DISABLE_FWD0         0x40u  /* separate lean kernel for the calls at the first base of each read                   */
+#define CS_DISABLE_PERSIST      0x80u  /* device-driven late iterations (one launch for the thin tail of the task chain)      */
+
+/* engine construction options: which derived arrays are materialised in HBM and how the working buffers are sized.
+ * cs_engine_options_default() fills the defaults (in brackets).  Everything optional is also skipped automatically when
+ * it does not fit next to the index; the mechanisms that need it are then off.  Results never depend on any of this. */
+typedef struct {
+	int32_t full_sa;          /* [1] full suffix array in HBM: SAL is one gather instead of a bwt_sa walk (bwt.c:86-96)       */
+	int32_t sa64;             /* [0] 8-byte suffix-array / inverse-SA entries even below 2^32 rows (what hg19 scale uses)      */
+	int32_t text_mode;        /* [1] 2-bit text + inverse suffix array (needs full_sa)                                        */
+	int32_t text_arrays;      /* [1] lcp[] / rep[] byte arrays (needs text_mode): re-seeding and round 3 from the text        */
+	int32_t jump_k;           /* [15] bi-interval table of every jump_k-mer, 6..15; 0 = none                                  */
+	int32_t kmer_filter;      /* [1] filter over all min_seed_len-mers of the text for the window lanes                       */
+	int32_t fused;            /* [0] 1: the fused one-lane-per-read kernel instead of the split forward/backward kernels      */
+	int32_t mem_cap;          /* [64] mems per read held in the first-pass arena (more go through the overflow records)       */
+	int64_t lep_arena_mb;     /* [32768] arena of the forward passes' left-extension points; smaller = more chunks per pass   */
+	int64_t max_raw_mb;       /* [24576] first-pass mem arena; smaller = a batch is processed in more sub-batches             */
+	int32_t r3_text_iter;     /* [4] forward launch after which round 3 starts on its side stream                             */
+	int32_t count_sal_merged; /* [0] 1: also count the distinct SA slots per 512 reads (cs_stats_t.sal_calls as the reference
+	                           *     counts them, comp_seed.cpp:2327-2345); costs one sort of the slots per call              */
+	int32_t verbose;          /* [0] progress lines on stderr                                                                 */
+	int32_t reserved[7];      /* must be 0 */
+} cs_engine_options_t;
 
 /* CSR result of one batch.  Read r owns mems[mem_off[r] .. mem_off[r+1]) sorted by info (comp_seed.cpp:2301) and
  * seeds[seed_off[r] .. seed_off[r+1]) in mem-then-slot order (comp_seed.cpp:2311-2325).  The arrays belong to the
@@ -82,8 +115,11 @@ typedef struct {
 	                              reference's count unless re-seeding calls were answered from the text (below)  */
 	uint64_t bwt_calls;        /* of those, served from HBM/L2, i.e. not by the on-device SST               */
 	uint64_t sal_queries;      /* SA slots requested                                                        */
-	uint64_t sal_calls;        /* SA slots actually walked (after on-device dedup)                          */
-	uint64_t overflow_reads;   /* reads that needed the large-capacity second pass                          */
+	uint64_t sal_calls;        /* distinct SA slots per 512 consecutive reads (what CompSeed looks up after merging,
+	                              comp_seed.cpp:2327-2345) when the engine was created with count_sal_merged;
+	                              otherwise == sal_queries.  The device looks every slot up: one gather each      */
+	uint64_t overflow_mems;    /* mems beyond a read's first mem_cap (split kernels), or reads that needed the
+	                              large-capacity second pass (fused kernel)                                        */
 	double   seed_kernel_ms;   /* accumulated HIP-event time of the first-pass SMEM kernel launches         */
 	double   sal_kernel_ms;    /* ... of the SAL kernels                                                    */
 	double   total_ms;         /* ... of whole seed calls, first launch to last                             */
@@ -116,18 +152,25 @@ void cs_index_free(cs_index_t *idx);
  *      bns_fasta2bntseq does with lrand48, bntseq.c:295); the reverse complement is appended internally.
  *      cs_index_save writes <prefix>.bwt / <prefix>.sa byte-identical to bwt_dump_bwt / bwt_dump_sa (bwt.c:385-407). */
 int  cs_index_build(const uint8_t *fwd_nt4, uint64_t l_pac, int device, cs_index_t **out);
+#define CS_BUILD_FORCE_64BIT 1u   /* run the 64-bit suffix sorter on a genome that would fit 32 bits (tests) */
+#define CS_BUILD_VERBOSE     2u
+int  cs_index_build_flags(const uint8_t *fwd_nt4, uint64_t l_pac, int device, uint32_t flags, cs_index_t **out);
 int  cs_index_save(const cs_index_t *idx, const char *prefix);
 
 /* ---- engine: uploads the index to GPU `device` once (replaces bwa_idx_load_from_shm's role: HBM residency) */
 int  cs_device_count(int *n);
-int  cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out);
+void cs_engine_options_default(cs_engine_options_t *o);
+int  cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out);            /* default options */
+int  cs_engine_create_opts(const cs_index_view_t *index, int device, const cs_engine_options_t *opts, cs_engine_t **out);
 void cs_engine_destroy(cs_engine_t *e);
 
 /* ---- the hot path.  `bases` holds the reads back to back (ASCII or already nt4-coded 0..4, as CompSeed accepts:
  *      comp_seed.cpp:2258-2260); read r is bases[offsets[r] .. offsets[r+1]).  The caller's buffers are not modified
  *      (the reference overwrites seq in place).  Host variant: pointers are host memory, results land in pinned host
  *      memory.  Device variant: pointers are device memory on the engine's GPU and the result arrays are device
- *      pointers (no PCIe traffic inside the call). */
+ *      pointers (no PCIe traffic inside the call).  The engine works on streams of its own: device inputs must be
+ *      COMPLETE when the call is made (synchronise the stream that produced them first), d_offsets[0] must be 0 and
+ *      d_offsets[n_reads] == n_bases (checked: CS_EINVAL); results are complete when the call returns. */
 int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                           const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
 int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,

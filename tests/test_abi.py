@@ -73,6 +73,46 @@ def test_params_default(lib):
     assert abs(p.split_factor - 1.5) < 1e-9
 
 
+def test_engine_options_default(lib):
+    import compseed_amd as ca
+    o = ca.EngineOptions()
+    assert (o.full_sa, o.sa64, o.text_mode, o.text_arrays, o.jump_k, o.kmer_filter, o.fused, o.mem_cap) == (1, 0, 1, 1, 15, 1, 0, 64)
+    assert (o.lep_arena_mb, o.max_raw_mb, o.count_sal_merged, o.verbose) == (32768, 24576, 0, 0) and not any(o.reserved)
+    with pytest.raises(TypeError):
+        ca.EngineOptions(no_such_option=1)
+
+
+def test_ctypes_structs_match_the_header(lib, tmp_path):
+    """sizeof / offsetof of every struct of include/compseed_amd.h as gcc sees them == the ctypes mirrors in binding.py"""
+    import ctypes
+    import subprocess
+    import compseed_amd.binding as b
+    structs = {"cs_index_view_t": b.IndexView, "cs_params_t": b.Params, "cs_result_t": b.CResult, "cs_stats_t": b.Stats,
+               "cs_engine_options_t": b.EngineOptions}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src.append("return 0; }")
+    c = tmp_path / "abi.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
+
+
+def test_product_reads_no_environment_switches():
+    """configuration goes through cs_params_t / cs_engine_options_t, not through getenv"""
+    for base, _, files in os.walk(os.path.join(ROOT, "compseed_amd", "csrc")):
+        for f in files:
+            assert "getenv" not in open(os.path.join(base, f), errors="replace").read(), f
+
+
 def test_product_does_not_touch_the_oracle():
     """oracle/ is test infrastructure: nothing under compseed_amd/ may include, link or load it."""
     for base, _, files in os.walk(os.path.join(ROOT, "compseed_amd")):

@@ -70,11 +70,10 @@ def test_builder_on_adversarial_texts():
         ix.close()
 
 
-def test_64bit_builder_instantiation(monkeypatch, tmp_path):
+def test_64bit_builder_instantiation(tmp_path):
     """genomes beyond 2^31 bp (hg19) use 64-bit suffix indices; the same code path must reproduce the bwaidx fixture"""
     import compseed_amd as ca
-    monkeypatch.setenv("CS_BUILD_64BIT", "1")
-    ix = ca.Index.build(_data.load_pac_forward(), 0)
+    ix = ca.Index.build(_data.load_pac_forward(), 0, force_64bit=True)
     f = _data.load_bwt_files()
     bwt, sa = ix.arrays()
     assert ix.view.primary == f["primary"] and np.array_equal(bwt, f["bwt"]) and np.array_equal(sa, f["sa"])

@@ -58,7 +58,7 @@ def test_golden_seeds(eng, name, pname):
     res = eng.seed_batch(bases, off, ca.Params(**kw))
     _check_against_golden(res, z)
     st = eng.stats()
-    if st["overflow_reads"] == 0:                       # (reads that overflow into the second pass are seeded twice)
+    if st["overflow_mems"] == 0:                        # (reads that overflow into the fused second pass are seeded twice)
         # the default configuration skips extensions the reference performs (text shortcuts, window scheme), so its count
         # is only bounded by the reference's; sst_mode=0 reproduces it exactly (test_device_sst_is_transparent)
         assert st["bwt_calls"] <= int(z["counters"][3])
@@ -139,31 +139,27 @@ def test_full_sa_agrees_with_walk_everywhere(eng):
     o.close()
 
 
-def test_sampled_sa_walk_path(monkeypatch):
-    """CS_FULL_SA=0: SAL walks bwt_invPsi from the 1-in-32 samples like the reference (bwt.c:86-96); same seeds"""
+def test_sampled_sa_walk_path():
+    """full_sa=0: SAL walks bwt_invPsi from the 1-in-32 samples like the reference (bwt.c:86-96); same seeds"""
     import compseed_amd as ca
-    monkeypatch.setenv("CS_FULL_SA", "0")
-    monkeypatch.setenv("CS_MEM_CAP", "8")   # also force most reads through the overflow second pass
     ix = ca.Index.load(_data.PREFIX)
-    e = ca.Engine(ix, 0)
+    e = ca.Engine(ix, 0, full_sa=0, mem_cap=8)   # mem_cap 8: also force most reads through the overflow records
     for name, pname in (("repeat100", "default"), ("ragged", "k14"), ("main100", "c50s20")):
         z, kw = _data.load_golden(name, pname)
         bases, off = _data.load_reads(name)
         _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-    assert e.stats()["overflow_reads"] > 0
+    assert e.stats()["overflow_mems"] > 0
     e.close(); ix.close()
 
 
-@pytest.mark.parametrize("mode", ["fused", "split"])
-def test_both_smem_kernels_match_golden(monkeypatch, mode):
+@pytest.mark.parametrize("fused", [1, 0])
+def test_both_smem_kernels_match_golden(fused):
     """the fused one-lane-per-read kernel and the forward / cooperative-backward kernels are two independent
     implementations of the same three rounds: both must reproduce the reference bit for bit"""
     import compseed_amd as ca
-    monkeypatch.setenv("CS_SMEM_MODE", mode)
-    monkeypatch.setenv("CS_MEM_CAP", "6")        # most reads overflow their first 6 slots: exercises both overflow paths
-    monkeypatch.setenv("CS_LEP_ARENA_MB", "1")   # tiny LEP arena: the forward queue is processed in many chunks
     ix = ca.Index.load(_data.PREFIX)
-    e = ca.Engine(ix, 0)
+    # mem_cap 6: most reads overflow their first 6 slots (both overflow paths); 1 MB LEP arena: the forward queue is processed in many chunks
+    e = ca.Engine(ix, 0, fused=fused, mem_cap=6, lep_arena_mb=1)
     for name, pname in _data.golden_runs():
         z, kw = _data.load_golden(name, pname)
         bases, off = _data.load_reads(name)
@@ -171,163 +167,148 @@ def test_both_smem_kernels_match_golden(monkeypatch, mode):
     e.close(); ix.close()
 
 
-def test_text_mode_is_transparent(monkeypatch):
-    """CS_TEXT_MODE=0 keeps unique matches on the FM index; the default finishes them on the 2-bit text and the inverse
-    suffix array.  Same intervals, same seeds, same bwt_extend query count as the reference, fewer real index reads."""
+@pytest.fixture(scope="module")
+def eng64():
+    """the instantiation hg19 scale runs: 8-byte suffix-array and inverse-suffix-array entries (rows >= 2^32 there)"""
     import compseed_amd as ca
     ix = ca.Index.load(_data.PREFIX)
-    calls = {}
-    monkeypatch.setenv("CS_R2_TEXT", "0")
-    monkeypatch.setenv("CS_TEXT_SWEEP", "0")
-    monkeypatch.setenv("CS_WINDOW", "0")
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CS_TEXT_MODE", mode)
-        e = ca.Engine(ix, 0)
-        for name, pname in _data.golden_runs():
-            z, kw = _data.load_golden(name, pname)
-            bases, off = _data.load_reads(name)
-            e.reset_stats()
-            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-            st = e.stats()
-            assert st["bwt_queries"] == int(z["counters"][3]) or st["overflow_reads"] > 0
-        e.reset_stats()
-        bases, off = _data.load_reads("main100")
-        e.seed_batch(bases, off, ca.Params())
-        calls[mode] = e.stats()["bwt_calls"]
-        e.close()
+    e = ca.Engine(ix, 0, sa64=1)
+    yield e
+    e.close()
     ix.close()
-    assert calls["1"] < calls["0"]
 
 
-def test_reseeding_from_the_text_is_transparent(monkeypatch):
-    """CS_R2_TEXT=0 runs every re-seeding call (bwamem.c:241-249) on the FM index; the default answers those of unique
-    SMEMs from the repeat-length / LCP arrays when the text can decide them.  Same mems and seeds as the reference either
-    way; with it on, some calls must actually have been answered from the text and fewer extensions evaluated."""
+@pytest.mark.parametrize("name,pname", _data.golden_runs())
+def test_golden_seeds_64bit_text_side(eng64, name, pname):
+    """every reference golden through fsa64 / isa64 / lcp / rep as the benchmark's index uses them"""
     import compseed_amd as ca
-    ix = ca.Index.load(_data.PREFIX)
-    tot = {}
-    monkeypatch.setenv("CS_WINDOW", "0")
-    monkeypatch.setenv("CS_TEXT_SWEEP", "0")
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CS_R2_TEXT", mode)
-        e = ca.Engine(ix, 0)
-        e.reset_stats()
-        for name, pname in _data.golden_runs():
-            z, kw = _data.load_golden(name, pname)
-            bases, off = _data.load_reads(name)
-            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-        tot[mode] = e.stats()
-        e.close()
-    ix.close()
-    assert tot["0"]["reseed_text_calls"] == 0
-    assert tot["1"]["reseed_text_calls"] > 0
-    assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
-    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
+    z, kw = _data.load_golden(name, pname)
+    bases, off = _data.load_reads(name)
+    eng64.reset_stats()
+    _check_against_golden(eng64.seed_batch(bases, off, ca.Params(**kw)), z)
+    off_all = eng64.seed_batch(bases, off, ca.Params(sst_mode=0, **kw))
+    _check_against_golden(off_all, z)
 
 
-def test_sweeps_read_off_the_text_are_transparent(monkeypatch):
-    """CS_TEXT_SWEEP=0 runs every backward sweep (bwt.c:325-345) on the FM index; the default reads the sweep of a
-    round-1 call off the text when its longest match is unique and agrees with the text back to the previous pivot."""
+def test_64bit_text_side_mechanisms_fire_and_sa_agrees(eng64):
     import compseed_amd as ca
-    ix = ca.Index.load(_data.PREFIX)
-    tot = {}
-    monkeypatch.setenv("CS_R2_TEXT", "0")
-    monkeypatch.setenv("CS_WINDOW", "0")
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CS_TEXT_SWEEP", mode)
-        e = ca.Engine(ix, 0)
-        e.reset_stats()
-        for name, pname in _data.golden_runs():
-            z, kw = _data.load_golden(name, pname)
-            bases, off = _data.load_reads(name)
-            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-        tot[mode] = e.stats()
-        e.close()
-    ix.close()
-    assert tot["0"]["sweep_text_calls"] == 0 and tot["1"]["sweep_text_calls"] > 0
-    assert tot["1"]["bwt_queries"] < tot["0"]["bwt_queries"]
-    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
+    eng64.reset_stats()
+    for name in ("main100", "sorted150"):
+        bases, off = _data.load_reads(name)
+        eng64.seed_batch(bases, off, ca.Params())
+    st = eng64.stats()
+    assert st["reseed_text_calls"] > 0 and st["sweep_text_calls"] > 0 and st["r3_text_seeds"] > 0
+    n = int(eng64._index.view.seq_len)
+    got = eng64.sa(np.arange(0, n + 1, dtype=np.uint64))          # sa_kernel poisons rows where fsa64 != the walk
+    assert not (got == np.uint64(0xdeadbeefdeadbeef)).any()
 
 
-def test_window_scheme_is_transparent(monkeypatch):
-    """CS_WINDOW=0 sweeps every LEP backward in lockstep like bwt.c:325-345; the default settles the short ends through
-    the k-mer jump table and lets every surviving end walk alone (smem_split.hpp, bwd_win_run).  Same mems, same seeds."""
+def _run_goldens(e, **pkw):
     import compseed_amd as ca
-    ix = ca.Index.load(_data.PREFIX)
-    tot = {}
-    monkeypatch.setenv("CS_R2_TEXT", "0")
-    monkeypatch.setenv("CS_TEXT_SWEEP", "0")
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CS_WINDOW", mode)
-        e = ca.Engine(ix, 0)
-        e.reset_stats()
-        for name, pname in _data.golden_runs():
-            z, kw = _data.load_golden(name, pname)
-            bases, off = _data.load_reads(name)
-            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-        tot[mode] = e.stats()
-        e.close()
-    ix.close()
-    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
-    assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
+    e.reset_stats()
+    per_run = {}
+    for name, pname in _data.golden_runs():
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        q0 = e.stats()["bwt_queries"]
+        _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw, **pkw)), z)
+        per_run[(name, pname)] = (e.stats()["bwt_queries"] - q0, int(z["counters"][3]))
+    return e.stats(), per_run
 
 
-def test_round3_from_the_text_is_transparent(monkeypatch):
-    """CS_R3_TEXT=0 computes every round-3 seed (bwt.c:357-381) on the FM index, beside rounds 1/2; the default runs
-    round 3 afterwards and takes the seeds that lie inside a unique round-1 SMEM from the text arrays."""
+# every exact shortcut of DESIGN.md section 4.2: (switch, the others that must be off so that the effect is isolated, what must
+# have fired with it on, which counter must drop)
+MECHANISMS = {
+    "text_mode": (("r2_text", "text_sweep", "window", "r3_text"), None, "bwt_calls"),
+    "r2_text": (("window", "text_sweep"), "reseed_text_calls", "bwt_calls"),
+    "text_sweep": (("r2_text", "window"), "sweep_text_calls", "bwt_queries"),
+    "window": (("r2_text", "text_sweep"), None, "bwt_calls"),
+    "r3_text": ((), "r3_text_seeds", "bwt_calls"),
+    "kmer_filter": ((), None, "bwt_calls"),
+    "fwd0": ((), None, None),
+}
+
+
+@pytest.mark.parametrize("mech", sorted(MECHANISMS))
+def test_each_shortcut_is_transparent(eng, mech):
+    """cs_params_t.disable switches one mechanism off: all 14 reference goldens with it off and on, identical mems and seeds,
+    and the mechanism must actually have fired / saved index reads"""
     import compseed_amd as ca
-    ix = ca.Index.load(_data.PREFIX)
-    tot = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CS_R3_TEXT", mode)
-        e = ca.Engine(ix, 0)
-        e.reset_stats()
-        for name, pname in _data.golden_runs():
-            z, kw = _data.load_golden(name, pname)
-            bases, off = _data.load_reads(name)
-            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-        tot[mode] = e.stats()
-        e.close()
-    ix.close()
-    assert tot["0"]["r3_text_seeds"] == 0 and tot["1"]["r3_text_seeds"] > 0
-    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
-    assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
+    others, fired, drops = MECHANISMS[mech]
+    base = ca.binding.disable_mask(*others)
+    st_off, runs_off = _run_goldens(eng, disable=base | ca.binding.disable_mask(mech))
+    st_on, _ = _run_goldens(eng, disable=base)
+    assert st_on["mems"] == st_off["mems"] and st_on["seeds"] == st_off["seeds"]
+    if fired:
+        assert st_off[fired] == 0 and st_on[fired] > 0
+    if drops:
+        assert st_on[drops] < st_off[drops]
+    if mech == "text_mode":  # with every query-skipping shortcut off the query count is the reference's, run by run
+        for key, (got, want) in runs_off.items():
+            assert got == want, key
 
 
-def test_kmer_filter_is_transparent(monkeypatch):
-    """CS_KMER_FILTER=0: the window lanes go straight to the jump table; default: they first ask a filter over all
-    min_seed_len-mers of the text whether their window occurs at all ("no" is exact).  Same mems, fewer index reads."""
+def test_all_shortcuts_off_by_flags_equals_reference_count(eng):
     import compseed_amd as ca
-    ix = ca.Index.load(_data.PREFIX)
-    tot = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CS_KMER_FILTER", mode)
-        e = ca.Engine(ix, 0)
-        e.reset_stats()
-        for name, pname in _data.golden_runs():
-            z, kw = _data.load_golden(name, pname)
-            bases, off = _data.load_reads(name)
-            _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
-        tot[mode] = e.stats()
-        e.close()
-    ix.close()
-    assert tot["1"]["mems"] == tot["0"]["mems"] and tot["1"]["seeds"] == tot["0"]["seeds"]
-    assert tot["1"]["bwt_calls"] < tot["0"]["bwt_calls"]
+    st, runs = _run_goldens(eng, disable=0xffffffff)
+    assert st["reseed_text_calls"] == 0 and st["sweep_text_calls"] == 0 and st["r3_text_seeds"] == 0
 
 
-@pytest.mark.parametrize("jk", ["0", "13", "9"])
-def test_other_jump_table_sizes(monkeypatch, jk):
-    """CS_JUMP_K: no jump table at all (forward passes and round 3 start base by base, no window scheme), or a smaller one
+@pytest.mark.parametrize("jk", [0, 13, 9])
+def test_other_jump_table_sizes(jk):
+    """jump_k: no jump table at all (forward passes and round 3 start base by base, no window scheme), or a smaller one
     (13-mers: six extensions from the table entry to min_seed_len; 9-mers: below the window scheme's range for -k 19)"""
     import compseed_amd as ca
-    monkeypatch.setenv("CS_JUMP_K", jk)
     ix = ca.Index.load(_data.PREFIX)
-    e = ca.Engine(ix, 0)
+    e = ca.Engine(ix, 0, jump_k=jk)
+    _run_goldens(e)
+    e.close(); ix.close()
+
+
+def test_without_optional_arrays():
+    """the degrade path of a part with little HBM: no text arrays, no text, no full SA -- each level must still be exact"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    for opts in (dict(text_arrays=0), dict(text_mode=0), dict(full_sa=0), dict(full_sa=0, jump_k=0, kmer_filter=0)):
+        e = ca.Engine(ix, 0, **opts)
+        st, _ = _run_goldens(e)
+        if "text_arrays" in opts or "text_mode" in opts or "full_sa" in opts:
+            assert st["reseed_text_calls"] == 0 and st["r3_text_seeds"] == 0
+        e.close()
+    ix.close()
+
+
+def test_sal_merged_count_is_the_references():
+    """count_sal_merged: cs_stats_t.sal_calls = distinct SA slots per 512 reads, CompSeed's 'SA Lookup ... calls' (comp_seed.cpp:2327-2345)"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0, count_sal_merged=1)
     for name, pname in _data.golden_runs():
         z, kw = _data.load_golden(name, pname)
         bases, off = _data.load_reads(name)
+        e.reset_stats()
         _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+        st = e.stats()
+        assert st["sal_queries"] == int(z["counters"][5]) and st["sal_calls"] == int(z["counters"][6]), (name, pname)
     e.close(); ix.close()
+
+
+def test_device_offsets_are_validated(eng):
+    """cs_engine_seed_batch_device: offsets that do not tile [0, n_bases) are CS_EINVAL, not an out-of-bounds read"""
+    import compseed_amd as ca
+    bases, off = _data.load_reads("sorted150")
+    d_b = eng.alloc(bases.nbytes + 64); eng.upload(d_b, bases)
+    n = off.size - 1
+    for bad in (off + np.uint64(1), np.concatenate([off[:-1], [off[-1] + np.uint64(4096)]]).astype(np.uint64),
+                np.concatenate([off[:5], [off[3]], off[6:]]).astype(np.uint64)):
+        d_o = eng.alloc(bad.nbytes); eng.upload(d_o, bad)
+        with pytest.raises(ca.CSError) as ei:
+            eng.seed_batch_device(d_b, d_o, n, bases.size)
+        assert ei.value.code == -1
+        eng.free(d_o)
+    d_o = eng.alloc(off.nbytes); eng.upload(d_o, off)
+    assert eng.seed_batch_device(d_b, d_o, n, bases.size).n_mems > 0      # and the engine is still usable afterwards
+    eng.free(d_o); eng.free(d_b)
 
 
 def test_cli_dump_matches_golden(tmp_path):

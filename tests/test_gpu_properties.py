@@ -100,7 +100,7 @@ def test_strand_symmetry(world):
     assert np.array_equal(ka, kb)
 
 
-def test_invariance_under_batching_sst_and_kernel_variant(world, monkeypatch):
+def test_invariance_under_batching_sst_and_kernel_variant(world):
     ca, eng, res = world["ca"], world["eng"], world["res"]
     hb, ho = world["bases"], world["off"]
     again = eng.seed_batch(hb, ho)                                          # determinism despite atomics / task order
@@ -111,8 +111,7 @@ def test_invariance_under_batching_sst_and_kernel_variant(world, monkeypatch):
     p1 = eng.seed_batch(hb[: cut * 150], ho[: cut + 1])
     p2 = eng.seed_batch(hb[cut * 150:], ho[cut:] - ho[cut])
     assert np.array_equal(np.concatenate([p1.mems, p2.mems]), res.mems) and np.array_equal(np.concatenate([p1.seeds, p2.seeds]), res.seeds)
-    monkeypatch.setenv("CS_SMEM_MODE", "fused")                             # second, independent implementation
-    e2 = ca.Engine(world["ix"], 0)
+    e2 = ca.Engine(world["ix"], 0, fused=1)                                 # second, independent implementation
     f = e2.seed_batch(hb[: 60000 * 150], ho[: 60001])
     e2.close()
     k = int(res.mem_off[60000])
