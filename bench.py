@@ -9,11 +9,23 @@ reads).  Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofl
     python bench.py                       # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+What the line holds besides the contract's fields:
+  parity          a STRIDED sample of every rank's batch (every (n/20000)-th read, so the whole genome with its repeats is
+                  covered) compared bit for bit with the oracle; a mismatch nulls `value` and the process exits 1
+  roofline        byte model of THIS implementation (bytes the kernels request from the index-side arrays, counted on the
+                  device by the counting instantiations in one extra pass) over the live HIP-event time of the SMEM stage;
+                  `traffic` = FETCH_SIZE of the same stage from a rocprofv3 --pmc child run of this very script (N = 1)
+  cpu_baseline    the oracle (CPU port) timed on this box's host cores on a bounded sample
+  pcie_inclusive  the host-buffer boundary call (H2D of reads, D2H of results), SURVEY 8(d)'s metric; never `value`
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -24,13 +36,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+STAGE_KERNELS = ("fwd0_kernel", "fwd_kernel", "bwd_win0_kernel", "bwd_win_kernel", "bwd_wide_kernel", "bwd_all_kernel", "r2text_kernel",
+                 "r3text_kernel", "tail_kernel", "smem_kernel")
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -39,14 +53,118 @@ def main():
                     help="synthetic genome size in Mbp (3100 = hg19 scale)")
     ap.add_argument("--reads", type=int, default=int(os.environ.get("CS_BENCH_READS", "10000000")), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--profile", default="default", help="workload profile of tools/synth.py (default = BASELINE configs[1] proxy)")
     ap.add_argument("--no-sal", action="store_true")
-    ap.add_argument("--host-io", action="store_true", help="also time the host-buffer variant (PCIe in and out) after the timed region")
-    ap.add_argument("--sst", type=int, default=int(os.environ.get("CS_BENCH_SST", "1")), help="on-device SST memo (1 = on, 0 = off)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (cs_engine_seed_batch)")
+    ap.add_argument("--sst", type=int, default=1, help="on-device SST memo and every shortcut (1 = on, 0 = the literal algorithm)")
+    ap.add_argument("--disable", default="", help="comma-separated shortcuts to switch off (cs_params_t.disable): " +
+                    "text_mode,r2_text,text_sweep,window,r3_text,kmer_filter,fwd0,persist")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (cs_engine_options_t), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--check-reads", type=int, default=20000, help="reads compared bit-for-bit against the oracle after the timed region")
+    ap.add_argument("--check-reads", type=int, default=20000, help="reads per rank compared bit-for-bit against the oracle (strided sample)")
+    ap.add_argument("--traffic", choices=["live", "none"], default="live",
+                    help="live: HBM bytes of the SMEM stage from a rocprofv3 --pmc FETCH_SIZE child run of this script (N = 1 only)")
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: the profiled child of --traffic live
+    ap.add_argument("--lib", default="", help="alternative build of libcompseed_amd.so (A/B experiments)")
     ap.add_argument("-k", type=int, default=19); ap.add_argument("-r", type=float, default=1.5)
     ap.add_argument("-y", type=int, default=20); ap.add_argument("-c", type=int, default=500); ap.add_argument("-s", type=int, default=10)
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def workload_args(args):
+    """the flags that define the workload, for the profiled child"""
+    out = ["--genome-mbp", str(args.genome_mbp), "--reads", str(args.reads), "--read-len", str(args.read_len), "--profile", args.profile,
+           "--sst", str(args.sst), "-k", str(args.k), "-r", str(args.r), "-y", str(args.y), "-c", str(args.c), "-s", str(args.s)]
+    if args.no_sal:
+        out.append("--no-sal")
+    if args.disable:
+        out += ["--disable", args.disable]
+    for o in args.opt:
+        out += ["--opt", o]
+    if args.lib:
+        out += ["--lib", args.lib]
+    return out
+
+
+def pmc_traffic(args):
+    """FETCH_SIZE of one pass of the SMEM stage, per kernel, from a rocprofv3 child run of this script (counters in a run of
+    their own with --kernel-trace only, as the guide prescribes).  Also the probe kernel's FETCH_SIZE per random 32-byte
+    record read (the calibration of the counter for this access shape) and per-kernel durations with the dispatches
+    serialised by the profiler.  Returns None when rocprofv3 is missing or the run fails."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    import csv
+    import glob
+    td = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
+    info = os.path.join(td, "child.json")
+    cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", os.path.join(td, "out"), "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", info] + workload_args(args)
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+    except Exception as ex:  # noqa: BLE001
+        log("rocprofv3 child failed: %r" % (ex,))
+        shutil.rmtree(td, ignore_errors=True)
+        return None
+    if r.returncode != 0 or not os.path.exists(info):
+        log("rocprofv3 child failed (rc %d): %s" % (r.returncode, r.stderr[-400:]))
+        shutil.rmtree(td, ignore_errors=True)
+        return None
+    child = json.load(open(info))
+    fetch, dur, calls = {}, {}, {}
+    probe_kib = None
+    for f in glob.glob(os.path.join(td, "out", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != "FETCH_SIZE":
+                continue
+            k = row["Kernel_Name"]
+            if "random_block_chain_kernel" in k:
+                probe_kib = float(row["Counter_Value"])
+                continue
+            name = next((n for n in STAGE_KERNELS if n in k), None)
+            if name == "fwd_kernel" and "fwd0_kernel" in k:
+                name = "fwd0_kernel"
+            if name == "bwd_win_kernel" and "bwd_win0_kernel" in k:
+                name = "bwd_win0_kernel"
+            if name:
+                fetch[name] = fetch.get(name, 0.0) + float(row["Counter_Value"]) * 1024.0
+                calls[name] = calls.get(name, 0) + 1
+                if "Start_Timestamp" in row and "End_Timestamp" in row:
+                    dur[name] = dur.get(name, 0.0) + (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+    shutil.rmtree(td, ignore_errors=True)
+    passes = max(1, int(child.get("passes", 1)))
+    if not fetch:
+        return None
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE child run of this script (%d pass(es), %.0f s)" % (passes, time.time() - t0),
+           "per_kernel_bytes": {k: v / passes for k, v in fetch.items()},
+           "per_kernel_ms_serialised": {k: v / passes for k, v in dur.items()} if dur else None,
+           "per_kernel_dispatches": {k: v / passes for k, v in calls.items()},
+           "stage_bytes": sum(fetch.values()) / passes}
+    if probe_kib and child.get("probe_record_reads"):
+        out["probe_fetch_bytes_per_random_record_read"] = probe_kib * 1024.0 / child["probe_record_reads"]
+    return out
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse_args()
+    if args.lib:
+        os.environ["CS_LIB"] = args.lib
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    traffic = None
+    if args.traffic == "live" and not args.pmc_child and world_env == 1:
+        traffic = pmc_traffic(args)  # before this process touches the GPU: the child needs the HBM
 
     import torch
     if not torch.cuda.is_available():
@@ -65,28 +183,44 @@ def main():
     # ---- workload: synthetic genome (same on every rank), index built on this rank's GPU, reads of this rank's share
     t0 = time.time()
     L = int(args.genome_mbp * 1e6)
-    G = synth.make_genome(L, seed=20261003, device=dev)
+    prof = synth.PROFILES[args.profile]
+    G = synth.make_genome(L, seed=20261003, device=dev, **prof["genome"])
     g_host = G.cpu().numpy()
     torch.cuda.synchronize()
     t1 = time.time()
     torch.cuda.empty_cache()
     ix = ca.Index.build(g_host, local)
+    del g_host
     t2 = time.time()
-    eng = ca.Engine(ix, local)
+    eopts = {}
+    for o in args.opt:
+        k, v = o.split("=", 1)
+        eopts[k] = int(v)
+    eng = ca.Engine(ix, local, **eopts)
     t3 = time.time()
-    bases, off = synth.make_reads(G, args.reads, args.read_len, seed=777 + rank, p_sub=0.005, sort=True,
-                                  lo_frac=rank / world, hi_frac=(rank + 1) / world)
+    rkw = dict(prof["reads"])
+    bases, off = synth.make_reads(G, args.reads, args.read_len, seed=777 + rank, lo_frac=rank / world, hi_frac=(rank + 1) / world, **rkw)
     n_bases = bases.numel()
     torch.cuda.synchronize()
     del G
     torch.cuda.empty_cache()
     if rank == 0:
-        log("genome %.0f Mbp: generate %.1fs, index build %.1fs (seq_len %d), upload %.1fs, reads %d x %d in %.1fs" %
-            (args.genome_mbp, t1 - t0, t2 - t1, ix.view.seq_len, t3 - t2, args.reads, args.read_len, time.time() - t3))
-    par = ca.Params(k=args.k, r=args.r, s=args.s, c=args.c, y=args.y, want_sal=0 if args.no_sal else 1, sst_mode=args.sst)
+        log("genome %.0f Mbp (%s): generate %.1fs, index build %.1fs (seq_len %d), engine %.1fs, reads %d x %d in %.1fs" %
+            (args.genome_mbp, args.profile, t1 - t0, t2 - t1, ix.view.seq_len, t3 - t2, args.reads, args.read_len, time.time() - t3))
+    dis = ca.disable_mask(*[d for d in args.disable.split(",") if d])
+    pk = dict(k=args.k, r=args.r, s=args.s, c=args.c, y=args.y, want_sal=0 if args.no_sal else 1, sst_mode=args.sst, disable=dis)
+    par = ca.Params(**pk)
 
-    def step():
-        return eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), args.reads, n_bases, par)
+    def step(p=par):
+        return eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), args.reads, n_bases, p)
+
+    if args.pmc_child:  # the profiled child of --traffic live: a calibration probe, a priming pass, one pass; then out
+        eng.probe_random_lines(4, 64)   # n_cu x 4 blocks of 256 lanes, 64 dependent random record reads each
+        probe_reads = int(torch.cuda.get_device_properties(local).multi_processor_count) * 4 * 256 * 64
+        step(); step()
+        json.dump({"passes": 2, "probe_record_reads": probe_reads}, open(args.pmc_child, "w"))
+        eng.close(); ix.close()
+        return 0
 
     if args.warmup == 0:
         step()  # never time the first call of an engine: it sizes and allocates the batch buffers (setup, like the index upload)
@@ -107,76 +241,106 @@ def main():
         "metric": "reads/sec (150bp) seeded", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "synthetic %.0f Mbp genome (Alu-like family 10%%, segdups, tandem arrays), %d x %d bp position-sorted "
-                               "reads per GPU per step, 0.5%% substitutions, -k %d -r %g -y %d -c %d%s" %
-                               (args.genome_mbp, args.reads, args.read_len, args.k, args.r, args.y, args.c, " (mems only)" if args.no_sal else " + SAL"),
-                   "genome_mbp": args.genome_mbp, "reads_per_gpu_per_step": args.reads, "read_len": args.read_len,
+        "config": {"workload": "%s; %d x %d bp %s reads per GPU per step; -k %d -r %g -y %d -c %d%s" %
+                               (prof["describe"](args.genome_mbp), args.reads, args.read_len, "position-sorted" if rkw.get("sort", True) else "shuffled",
+                                args.k, args.r, args.y, args.c, " (mems only)" if args.no_sal else " + SAL"),
+                   "profile": args.profile, "genome_mbp": args.genome_mbp, "reads_per_gpu_per_step": args.reads, "read_len": args.read_len,
                    "parallelism": "reads sharded over %d GPU(s), index replicated" % world},
     }
 
+    # ---- parity gate on EVERY rank: a strided sample of this rank's batch against the oracle (the checker, never the product)
+    import _oracle
+    ncpu_share = max(1, len(os.sched_getaffinity(0)) // max(1, torch.cuda.device_count() if world > 1 else 1))
+    cores = min(ncpu_share, 16)
+    bwt_words, sa = ix.arrays()
+    oidx = _oracle.OracleIndex.from_arrays(ix.view.primary, [ix.view.L2[i] for i in range(1, 5)], bwt_words, sa, 32)
+    opar = _oracle.make_params(k=args.k, r=args.r, s=args.s, c=args.c, y=args.y)
+    nchk = min(args.check_reads, args.reads)
+    stride = max(1, args.reads // max(1, nchk))
+    ids = np.arange(0, args.reads, stride, dtype=np.uint64)[:nchk]
+    nchk = ids.size
+    sel = (ids[:, None].astype(np.int64) * args.read_len + np.arange(args.read_len)[None, :]).reshape(-1)
+    hb = bases[torch.from_numpy(sel).to(dev)].cpu().numpy()
+    ho = np.arange(nchk + 1, dtype=np.uint64) * np.uint64(args.read_len)
+    want = oidx.seed_batch(hb, ho, opar, mode=1, sst_batch=512, want_sal=not args.no_sal, threads=cores)
+    got = eng.gather_reads(ids)
+    ok = np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"])
+    if not args.no_sal:
+        ok = ok and np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
+    all_ok = D.sum_over_ranks(0.0 if ok else 1.0) == 0.0
+    if not ok:
+        log("PARITY FAILURE on rank %d against the oracle (strided sample of %d reads)" % (rank, nchk))
+
     if rank == 0:
-        # ---- parity gate + algorithmic bytes + CPU baseline, all on a bounded prefix of rank 0's reads (oracle = checker)
-        import _oracle
-        bwt_words, sa = ix.arrays()
-        oidx = _oracle.OracleIndex.from_arrays(ix.view.primary, [ix.view.L2[i] for i in range(1, 5)], bwt_words, sa, 32)
-        opar = _oracle.make_params(k=args.k, r=args.r, s=args.s, c=args.c, y=args.y)
-        nchk = min(args.check_reads, args.reads)
-        hb = bases[: nchk * args.read_len].cpu().numpy(); ho = off[: nchk + 1].cpu().numpy().astype(np.uint64)
-        want = oidx.seed_batch(hb, ho, opar, mode=1, sst_batch=512, want_sal=not args.no_sal, threads=min(16, len(os.sched_getaffinity(0))))
-        mo = eng.download(res.ptr["mem_off"], np.uint64, nchk + 1)
-        nm = int(mo[-1])
-        mm = eng.download(res.ptr["mems"], ca.INTV_DT, nm)
-        ok = np.array_equal(mo, want["mem_off"]) and np.array_equal(mm, want["mems"])
-        if not args.no_sal:
-            so = eng.download(res.ptr["seed_off"], np.uint64, nchk + 1)
-            ss = eng.download(res.ptr["seeds"], ca.SEED_DT, int(so[-1]))
-            ok = ok and np.array_equal(so, want["seed_off"]) and np.array_equal(ss, want["seeds"])
-        out["parity"] = {"checked_reads": nchk, "bit_exact_vs_oracle": bool(ok)}
-        if not ok:
-            log("PARITY FAILURE against the oracle on the first %d reads" % nchk)
+        out["parity"] = {"checked_reads_per_rank": int(nchk), "stride": int(stride), "ranks_checked": world, "bit_exact_vs_oracle": bool(all_ok)}
         ws = want["stats"]
-        # algorithmic bytes of the SMEM kernel per read: 64 B x Occ blocks of the REAL bwt_extend calls under the
-        # reference's cache policy (fresh SSTs per 512 reads) + the read itself + 32 B per mem written
-        unc = oidx.seed_batch(hb, ho, opar, mode=0, want_sal=False, threads=min(16, len(os.sched_getaffinity(0))))["stats"]
-        per_read = (64.0 * ws["bwt_blocks"] + 32.0 * ws["n_mems"]) / nchk + args.read_len
-        per_read_unc = (64.0 * unc["bwt_blocks_uncached"] + 32.0 * ws["n_mems"]) / nchk + args.read_len
-        # The SMEM stage is the dominant device work.  In the default (split) mode one pass over a batch = a short chain of
-        # fwd_kernel / bwd_all_kernel launches; their summed duration per pass is measured with HIP events on the engine's
-        # stream (first launch to last) and must agree with rocprofv3's TotalDurationNs(fwd_kernel)+(bwd_all_kernel) per pass.
+        # ---- roofline.  Stage = every launch of one pass of the SMEM collection (fwd0 / fwd / bwd_* / r2text / r3text [/ tail]);
+        # its time per pass is measured live with HIP events on the engine's stream over the timed region (seed_kernel_ms).
         launches = max(1, st["seed_kernel_launches"])          # passes of the stage (1 per step unless the batch is split)
         kern_ms = st["seed_kernel_ms"] / launches
         reads_per_launch = args.reads * args.steps / launches
-        achieved = per_read * reads_per_launch / (kern_ms * 1e-3) / 1e9
-        fused = os.environ.get("CS_SMEM_MODE", "") == "fused"
-        pmc = None
-        try:  # HBM bytes per pass from the committed PMC run of this workload (tools/pmc.sh), if there is one
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = "%g_%d_%d" % (args.genome_mbp, args.reads, args.read_len)
-            pmc = pm.get(key, {}).get("smem_stage_bytes_per_pass")
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": pmc, "kernel": "smem_kernel" if fused else "SMEM stage = all fwd0 / fwd / bwd_win / bwd_win0 / bwd_wide / r2text / r3text launches of one pass",
-                           "traffic_GBps": (pmc / (kern_ms * 1e-3) / 1e9) if pmc else None,
-                           "traffic_frac": (pmc / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc else None,
-                           "note": "achieved/frac use SURVEY 8(d)'s algorithmic bytes = what the REFERENCE's bwt_extend calls touch; the kernels answer most of "
-                                   "those calls from a jump table and text-side arrays (DESIGN.md 4.2), so real traffic is several times lower and frac can exceed 1; "
-                                   "traffic_frac is the fetched bytes over the same time over the same peak",
-                           "kernel_ms_per_launch": kern_ms, "launches": launches,
-                           "algorithmic_bytes_per_read": per_read, "uncached_bytes_per_read": per_read_unc,
-                           "bwt_extend_queries_per_read": st["bwt_queries"] / (args.reads * args.steps),
-                           "device_sst_hit_rate": 1.0 - st["bwt_calls"] / max(1, st["bwt_queries"]),
-                           "reference_sst_hit_rate": 1.0 - ws["bwt_calls"] / max(1, ws["bwt_queries"]),
-                           "reference_bwt_extend_queries_per_read": ws["bwt_queries"] / nchk,
-                           "round3_seeds_from_text_per_read": st["r3_text_seeds"] / (args.reads * args.steps),
-                           "sweeps_read_off_the_text_per_read": st["sweep_text_calls"] / (args.reads * args.steps),
-                           "reseed_calls_answered_from_text_per_read": st["reseed_text_calls"] / (args.reads * args.steps),
-                           "reseed_calls_of_unique_smems_left_to_index_per_read": st["reseed_index_calls"] / (args.reads * args.steps),
-                           "sal_ms_per_step": st["sal_kernel_ms"] / args.steps, "total_gpu_ms_per_step": st["total_ms"] / args.steps,
-                           "overflow_reads_per_step": st["overflow_reads"] / args.steps,
-                           "overflow_pass_ms_per_step": st["overflow_kernel_ms"] / args.steps}
+        # byte model of this implementation: one extra pass with the counting instantiations of the kernels (same work, same
+        # results; the counts are exact and do not depend on timing)
+        eng.reset_stats()
+        step(ca.Params(count_traffic=1, **pk))
+        tm = eng.traffic_model()
+        st_c = eng.stats()
+        model_bytes = tm["bytes"] * (reads_per_launch / args.reads)
+        achieved = model_bytes / (kern_ms * 1e-3) / 1e9
+        # the reference's algorithm on the same reads (SURVEY 8d's count: 64 B x Occ blocks of its real bwt_extend calls under the
+        # 512-read SST policy + read + mems), from the oracle on the strided sample; NOT a roofline of this implementation
+        ref_per_read = (64.0 * ws["bwt_blocks"] + 32.0 * ws["n_mems"]) / nchk + args.read_len
+        kernels = {}
+        for name, kd in tm["kernels"].items():
+            kernels[name] = {"model_bytes": kd["bytes"], "events": kd["events"]}
+        if traffic:
+            for name, b in traffic["per_kernel_bytes"].items():
+                kernels.setdefault(name, {})["fetch_size_bytes"] = b
+                if traffic.get("per_kernel_ms_serialised"):
+                    kernels[name]["ms_serialised"] = traffic["per_kernel_ms_serialised"].get(name)
+                    kernels[name]["dispatches"] = traffic["per_kernel_dispatches"].get(name)
+            for name, kd in kernels.items():
+                if kd.get("fetch_size_bytes") and kd.get("ms_serialised"):
+                    kd["fetch_frac_of_peak_serialised"] = kd["fetch_size_bytes"] / (kd["ms_serialised"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        stage_traffic = traffic["stage_bytes"] if traffic else None
+        nq = max(1, st["bwt_queries"])
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": stage_traffic,
+            "kernel": "SMEM stage = all fwd0 / fwd / bwd_win / bwd_win0 / bwd_wide / r2text / r3text launches of one pass (%d reads)" % int(reads_per_launch),
+            "kernel_ms_per_launch": kern_ms, "launches": launches,
+            "model": "bytes the kernels request from the index-side arrays (32-B Occ records, jump entries, filter words, SA / inverse-SA "
+                     "entries, text words, rep/lcp bytes, LEP entries) counted on the device + streamed queue / read / mem bytes "
+                     "(cs_engine_traffic_model); a lower bound of what this implementation has to fetch",
+            "model_bytes_per_launch": model_bytes, "model_bytes_per_read": model_bytes / reads_per_launch,
+            "model_stream_bytes_per_launch": tm["stream_bytes"] * (reads_per_launch / args.reads),
+            "traffic_GBps": (stage_traffic / (kern_ms * 1e-3) / 1e9) if stage_traffic else None,
+            "traffic_frac": (stage_traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if stage_traffic else None,
+            "wasted_traffic_ratio": (stage_traffic / model_bytes) if stage_traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
+            "traffic_calibration": ({"fetch_size_bytes_per_random_32B_record_read": traffic.get("probe_fetch_bytes_per_random_record_read"),
+                                     "note": "FETCH_SIZE of the bare random-record probe kernel / its record reads; the guide's x2 correction is for wide "
+                                             "coalesced streams, this is the calibration for the path's own access shape; `traffic` is the raw counter"}
+                                    if traffic else None),
+            "kernels": kernels,
+            "reference_work_GBps": ref_per_read * reads_per_launch / (kern_ms * 1e-3) / 1e9,
+            "reference_bytes_per_read": ref_per_read,
+            "reference_note": "SURVEY 8(d)'s bytes of the REFERENCE's algorithm over the same time: how fast the reference's work gets done, "
+                              "not a fraction of the roofline (most of its bwt_extend calls are answered here without the FM index)",
+            "bwt_extend_queries_per_read": st["bwt_queries"] / (args.reads * args.steps),
+            "fm_index_calls_per_read": st["bwt_calls"] / (args.reads * args.steps),
+            "answered_without_fm_index": 1.0 - st["bwt_calls"] / nq,
+            "reference_sst_hit_rate": 1.0 - ws["bwt_calls"] / max(1, ws["bwt_queries"]),
+            "reference_bwt_extend_queries_per_read": ws["bwt_queries"] / nchk,
+            "round3_seeds_from_text_per_read": st["r3_text_seeds"] / (args.reads * args.steps),
+            "sweeps_read_off_the_text_per_read": st["sweep_text_calls"] / (args.reads * args.steps),
+            "reseed_calls_answered_from_text_per_read": st["reseed_text_calls"] / (args.reads * args.steps),
+            "reseed_calls_of_unique_smems_left_to_index_per_read": st["reseed_index_calls"] / (args.reads * args.steps),
+            "sal_ms_per_step": st["sal_kernel_ms"] / args.steps, "total_gpu_ms_per_step": st["total_ms"] / args.steps,
+            "overflow_mems_per_step": st["overflow_mems"] / args.steps,
+            "counting_pass_stage_ms": st_c["seed_kernel_ms"],
+            "mems_per_read": st["mems"] / (args.reads * args.steps), "seeds_per_read": st["seeds"] / (args.reads * args.steps)}
         if args.cpu_seconds > 0:
-            cores = min(len(os.sched_getaffinity(0)), 16 * max(1, torch.cuda.device_count()))  # the box's CPU share: 16 per GPU
             probe_n = min(nchk, 20000)
             tp = time.perf_counter()
             oidx.seed_batch(hb[: probe_n * args.read_len], ho[: probe_n + 1], opar, mode=1, want_sal=not args.no_sal, threads=cores)
@@ -187,20 +351,30 @@ def main():
             oidx.seed_batch(cb, co, opar, mode=1, sst_batch=512, want_sal=not args.no_sal, threads=cores)
             dt = time.perf_counter() - tp
             out["cpu_baseline"] = {"value": ncpu / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+                                   "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cpus": len(os.sched_getaffinity(0)),
                                    "sample": "first %d reads of rank 0's batch, oracle/cs_oracle.c in CompSeed mode (SST per 512 reads), %d threads, %.1f s"
                                              % (ncpu, cores, dt)}
-        if args.host_io:  # the boundary's host-buffer form: reads from pageable host memory, results into pinned host memory
+            del cb, co
+        if not args.no_host_io:  # the boundary's host-buffer form (SURVEY 8d's metric includes H2D of reads and D2H of results)
             hb_all = bases.cpu().numpy(); ho_all = off.cpu().numpy().astype(np.uint64)
-            eng.seed_batch(hb_all, ho_all, par, copy=False)  # warm-up: pinned result buffers are allocated on first use
+            eng.seed_batch(hb_all, ho_all, par, copy=False)  # warm-up: pinned buffers are allocated on first use
+            reps = 2
             tp = time.perf_counter()
-            eng.seed_batch(hb_all, ho_all, par, copy=False)
-            dt = time.perf_counter() - tp
+            for _ in range(reps):
+                eng.seed_batch(hb_all, ho_all, par, copy=False)
+            dt = (time.perf_counter() - tp) / reps
             out["pcie_inclusive"] = {"reads_per_s": args.reads / dt, "ms_per_step": 1e3 * dt,
-                                     "note": "cs_engine_seed_batch: H2D of the reads + D2H of mems and seeds, not overlapped; never `value`"}
+                                     "note": "cs_engine_seed_batch on rank 0: reads from pageable host memory, mems and seeds into host memory; never `value`"}
+            del hb_all, ho_all
+        if not all_ok:
+            out["value"] = None
+            out["error"] = "results differ from the oracle: the throughput above is void"
         print(json.dumps(out), flush=True)
+    oidx.close()
     D.close()
     eng.close(); ix.close()
+    return 0 if all_ok else 1
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

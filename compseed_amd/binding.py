@@ -13,7 +13,7 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
            "cs_index_build_flags", "cs_index_save",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
-           "cs_engine_seed_batch_device", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
+           "cs_engine_seed_batch_device", "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync"]
 
@@ -33,10 +33,10 @@ class Params(C.Structure):
     """cs_params_t; defaults = mem_opt_init (mapping/comp_seed.cpp:26-58)."""
     _fields_ = [("min_seed_len", C.c_int32), ("split_factor", C.c_float), ("split_width", C.c_int32),
                 ("max_occ", C.c_int32), ("max_mem_intv", C.c_uint64), ("want_sal", C.c_int32), ("sst_mode", C.c_int32),
-                ("disable", C.c_uint32)]
+                ("disable", C.c_uint32), ("count_traffic", C.c_uint32)]
 
-    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=1, disable=0):
-        super().__init__(k, r, s, c, y, want_sal, sst_mode, disable)
+    def __init__(self, k=19, r=1.5, s=10, c=500, y=20, want_sal=1, sst_mode=1, disable=0, count_traffic=0):
+        super().__init__(k, r, s, c, y, want_sal, sst_mode, disable, count_traffic)
 
 
 # cs_params_t.disable bits (include/compseed_amd.h CS_DISABLE_*)
@@ -82,6 +82,33 @@ class Stats(C.Structure):
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+KERNELS = ["fwd0_kernel", "fwd_kernel", "bwd_win_kernel", "bwd_win0_kernel", "bwd_wide_kernel", "bwd_all_kernel", "r2text_kernel",
+           "r3text_kernel", "smem_kernel"]
+EVENTS = ["occ_record", "jump_entry", "filter_word", "sa_entry", "isa_entry", "text_word", "rep_load", "lcp_byte", "lep_entry", "mem_record"]
+
+
+class Traffic(C.Structure):
+    _fields_ = [("events", (C.c_uint64 * 10) * 9), ("event_bytes", C.c_uint64 * 10), ("stream_bytes", C.c_uint64)]
+
+
+class Digest(C.Structure):
+    _fields_ = [("mem_off", C.c_uint64), ("mems", C.c_uint64), ("seed_off", C.c_uint64), ("seeds", C.c_uint64)]
+
+    def astuple(self):
+        return (self.mem_off, self.mems, self.seed_off, self.seeds)
+
+
+def digest_words(a):
+    """host restatement of cs_engine_result_digest for one array (any dtype, viewed as 64-bit words)"""
+    w = np.ascontiguousarray(a).view(np.uint8).view("<u8").astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = w + np.arange(w.size, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(np.add.reduce(z, dtype=np.uint64)) if z.size else 0
 
 
 def lib_path():
@@ -132,6 +159,9 @@ def load_library():
     L.cs_engine_destroy.restype = None
     L.cs_engine_seed_batch.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.POINTER(CResult)]
     L.cs_engine_seed_batch_device.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.c_uint64, C.POINTER(CResult)]
+    L.cs_engine_result_digest.argtypes = [vp, C.POINTER(Digest)]
+    L.cs_engine_gather_reads.argtypes = [vp, i64, vp, C.POINTER(CResult)]
+    L.cs_engine_traffic_model.argtypes = [vp, C.POINTER(Traffic)]
     L.cs_engine_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cs_engine_reset_stats.argtypes = [vp]
     L.cs_engine_reset_stats.restype = None
@@ -290,6 +320,36 @@ class Engine:
         _check(self._L.cs_engine_seed_batch_device(self._h, C.byref(params), int(n_reads), C.c_void_p(d_bases), C.c_void_p(d_offsets),
                                                    int(n_bases), C.byref(res)))
         return Result(res, True, bool(params.want_sal))
+
+    def result_digest(self):
+        """(mem_off, mems, seed_off, seeds) digests of the result of the last seed call, computed on the device"""
+        d = Digest()
+        _check(self._L.cs_engine_result_digest(self._h, C.byref(d)))
+        return d.astuple()
+
+    def gather_reads(self, read_ids, copy=True):
+        """CSR slice of the selected reads of the last result (cs_engine_gather_reads) as a host Result"""
+        ids = np.ascontiguousarray(read_ids, dtype=np.uint64)
+        res = CResult()
+        _check(self._L.cs_engine_gather_reads(self._h, ids.size, ids.ctypes.data, C.byref(res)))
+        return Result(res, False, bool(res.seed_off), copy)
+
+    def traffic_model(self):
+        """byte model of the SMEM stage since the last reset_stats(): {"kernels": {name: {"bytes": B, "events": {event: n}}}, "stream_bytes": S,
+        "bytes": total} (cs_engine_traffic_model)"""
+        t = Traffic()
+        _check(self._L.cs_engine_traffic_model(self._h, C.byref(t)))
+        eb = [int(x) for x in t.event_bytes]
+        out = {"kernels": {}, "stream_bytes": int(t.stream_bytes), "event_bytes": dict(zip(EVENTS, eb))}
+        tot = int(t.stream_bytes)
+        for k, name in enumerate(KERNELS):
+            ev = [int(x) for x in t.events[k]]
+            if any(ev):
+                b = sum(n * w for n, w in zip(ev, eb))
+                out["kernels"][name] = {"bytes": b, "events": {e: n for e, n in zip(EVENTS, ev) if n}}
+                tot += b
+        out["bytes"] = tot
+        return out
 
     def stats(self):
         st = Stats()

@@ -43,7 +43,7 @@ extern "C" void cs_params_default(cs_params_t *p)
 {
 	if (!p) return;
 	p->min_seed_len = 19; p->split_factor = 1.5f; p->split_width = 10; p->max_occ = 500; p->max_mem_intv = 20;
-	p->want_sal = 1; p->sst_mode = 1; p->disable = 0;
+	p->want_sal = 1; p->sst_mode = 1; p->disable = 0; p->count_traffic = 0;
 }
 extern "C" void cs_engine_options_default(cs_engine_options_t *o)
 {
@@ -120,6 +120,9 @@ struct cs_engine {
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
 	size_t lep_arena_bytes = (size_t)32 << 30;
 	cs_stats_t st{};
+	DevBuf<unsigned long long> d_evc; uint64_t stream_bytes = 0; // byte model: event counters [N_KID][N_EV] on the device, stream part on the host
+	struct { bool valid = false; int64_t n_reads = 0; uint64_t n_mems = 0, n_seeds = 0; int want_sal = 0; } last; // the result held in d_mems / d_seeds
+	DevBuf<uint64_t> d_sel, d_sel_moff, d_sel_soff; DevBuf<OutMem> d_sel_mems; DevBuf<OutSeed> d_sel_seeds;
 	uint32_t cap = 64;          // mems per read kept by the first pass
 	size_t max_raw_bytes = (size_t)24 << 30;
 	int blocks_per_cu = 2;
@@ -252,9 +255,9 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	if (e->h_sctr.p[0]) return fail(CS_ERANGE, "a single base occurs 2^32 times or more: 32-bit Occ counts of the device layout overflow");
 	{
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fwd_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_fwd = std::min(nb, 8);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_all_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_bwd = std::min(nb, 8);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_win_kernel<256>, 256, 0) == hipSuccess && nb > 0) e->occ_win = std::min(nb, 8);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fwd_kernel<256, false>, 256, 0) == hipSuccess && nb > 0) e->occ_fwd = std::min(nb, 8);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_all_kernel<256, false>, 256, 0) == hipSuccess && nb > 0) e->occ_bwd = std::min(nb, 8);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bwd_win_kernel<256, false>, 256, 0) == hipSuccess && nb > 0) e->occ_win = std::min(nb, 8);
 		(void)hipGetLastError();
 	}
 	e->smem_mode = opt.fused ? 0 : 1;
@@ -264,6 +267,9 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	CS_TRY(e->d_ctr.reserve(8));
 	CS_TRY(e->h_ctr.reserve(8));
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 8 * sizeof(unsigned long long), e->stream));
+	static_assert(N_KID == CS_N_KERNELS && N_EV == CS_N_EVENTS, "cs_traffic_t mirrors the device-side event table");
+	CS_TRY(e->d_evc.reserve((size_t)N_KID * N_EV));
+	HIP_TRY(hipMemsetAsync(e->d_evc.p, 0, (size_t)N_KID * N_EV * sizeof(unsigned long long), e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 
 	DevIndex &ix = e->ix;
@@ -397,6 +403,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
 	e->d_fqA.release(); e->d_fqB.release(); e->d_fqR.release(); e->d_sst2.release(); e->d_jump.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
+	e->d_evc.release(); e->d_sel.release(); e->d_sel_moff.release(); e->d_sel_soff.release(); e->d_sel_mems.release(); e->d_sel_seeds.release();
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -418,7 +425,27 @@ extern "C" int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st)
 	*st = e->st;
 	return CS_OK;
 }
-extern "C" void cs_engine_reset_stats(cs_engine_t *e) { if (e) memset(&e->st, 0, sizeof e->st); }
+extern "C" void cs_engine_reset_stats(cs_engine_t *e)
+{
+	if (!e) return;
+	memset(&e->st, 0, sizeof e->st);
+	e->stream_bytes = 0;
+	(void)hipSetDevice(e->device);
+	(void)hipMemsetAsync(e->d_evc.p, 0, (size_t)N_KID * N_EV * sizeof(unsigned long long), e->stream);
+	(void)hipStreamSynchronize(e->stream);
+}
+extern "C" int cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out)
+{
+	if (!e || !out) return fail(CS_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMemcpyAsync(&out->events[0][0], e->d_evc.p, (size_t)N_KID * N_EV * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	const uint64_t sa_b = e->ix.fsa64 ? 8 : 4;
+	const uint64_t eb[N_EV] = {32, 16, 8, sa_b, sa_b, 4, 8, 1, 16, 32};
+	for (int i = 0; i < N_EV; ++i) out->event_bytes[i] = eb[i];
+	out->stream_bytes = e->stream_bytes;
+	return CS_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ helpers
 struct U32ToU64 { __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; } };
@@ -513,7 +540,7 @@ static int launch_smem(cs_engine *e, const cs_params_t *par, const uint64_t *d_o
 	unsigned blocks = (unsigned)std::min<int64_t>((int64_t)e->n_cu * e->blocks_per_cu, (n_tasks + SMEM_BLOCK - 1) / SMEM_BLOCK);
 	if (blocks == 0) return CS_OK;
 	const int SMEM_LEP_LDS = g_lep_lds;
-	blocks = (unsigned)std::min<int64_t>((int64_t)e->n_cu * (SMEM_LEP_LDS <= 10 ? 4 : SMEM_LEP_LDS <= 13 ? 3 : 2), (n_tasks + SMEM_BLOCK - 1) / SMEM_BLOCK);
+	blocks = (unsigned)std::min<int64_t>((int64_t)e->n_cu * 2, (n_tasks + SMEM_BLOCK - 1) / SMEM_BLOCK);
 	uint32_t spill_cap = max_len + 1 > (uint32_t)SMEM_LEP_LDS ? max_len + 1 - SMEM_LEP_LDS : 1;
 	// long reads: fewer resident workgroups rather than an unbounded spill area (one LEP list per lane, worst case = read length)
 	size_t per_block = (size_t)SMEM_BLOCK * spill_cap * sizeof(uint4);
@@ -526,12 +553,11 @@ static int launch_smem(cs_engine *e, const cs_params_t *par, const uint64_t *d_o
 	A.split_len = (int)(1.0 * par->min_seed_len * par->split_factor + .499); // comp_seed.cpp:2279 (double arithmetic)
 	A.split_width = (uint32_t)par->split_width;
 	A.max_mem_intv = par->max_mem_intv;
-	A.task_counter = e->d_ctr.p; A.spill = e->d_spill.p; A.spill_cap = spill_cap; A.n_queries = e->d_ctr.p + 1;
+	A.task_counter = e->d_ctr.p; A.spill = e->d_spill.p; A.spill_cap = spill_cap; A.n_queries = e->d_ctr.p + 1; A.evc = e->d_evc.p;
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, sizeof(unsigned long long), e->stream));
 	HIP_TRY(hipEventRecord(e->ev[0], e->stream));
-	if (SMEM_LEP_LDS == 20) hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 20>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
-	else if (SMEM_LEP_LDS == 13) hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 13>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
-	else hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 10>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
+	if (par->count_traffic) hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 20, true>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
+	else hipLaunchKernelGGL((smem_kernel<SMEM_BLOCK, 20, false>), dim3(blocks), dim3(SMEM_BLOCK), 0, e->stream, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[1], e->stream));
 	if (d_ids) e->st.overflow_kernel_launches++; else e->st.seed_kernel_launches++;
@@ -571,6 +597,12 @@ static int build_kmer_filter(cs_engine *e, int k)
 // Runs the three rounds for reads [0, nb) of d_off with fwd_kernel / bwd_kernel (smem_split.hpp).  On return d_cnt holds
 // the number of mems per read, d_out the first `cap` of each, d_ovfrec/*n_ovf the rest.  Returns 1 when a task queue
 // overflowed (the caller then falls back to the fused kernel for this sub-batch).
+// launch the counting instantiation of a kernel (cs_params_t.count_traffic) or the plain one
+#define LAUNCH_CT(count, KERN, grid, stream, ...)                                                              \
+	do {                                                                                                       \
+		if (count) hipLaunchKernelGGL((KERN<256, true>), grid, dim3(256), 0, stream, __VA_ARGS__);             \
+		else hipLaunchKernelGGL((KERN<256, false>), grid, dim3(256), 0, stream, __VA_ARGS__);                  \
+	} while (0)
 static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, int64_t nb, uint32_t max_len, uint64_t *n_ovf_out);
 static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *d_off, int64_t nb, uint32_t max_len, uint64_t *n_ovf_out)
 {
@@ -587,6 +619,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 {
 	hipStream_t s = e->stream;
 	const uint32_t dis = par->sst_mode != 0 ? par->disable : ~0u; // sst_mode 0: the literal algorithm, every shortcut off
+	const bool count = par->count_traffic != 0;
 	*n_ovf_out = 0;
 	if (par->split_width > 16382) return 1; // min_intv does not fit the 14-bit task field: use the fused kernel
 	const uint32_t stride = max_len + 1;
@@ -614,6 +647,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 	A.bq = e->d_bq.p;
 	A.lep = e->d_lep.p; A.lep_stride = stride;
 	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p; A.jump = e->jump_k ? e->d_jump.p : nullptr; A.jump_k = e->jump_k;
+	A.evc = e->d_evc.p;
 	A.fq_cap = fq_cap; A.n_f_next = C + 1; A.n_btasks = C + 13; A.n_text_sweeps = C + 14;
 	A.text_sweep = (dis & CS_DISABLE_TEXT_SWEEP) ? 0 : 1;
 	// window scheme for the backward sweeps (smem_split.hpp, bwd_win_run): needs the jump table and jump_k <= min_seed_len <= jump_k + 4
@@ -641,7 +675,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 		HIP_TRY(hipEventRecord(e->ev_r3a, s));
 		HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_r3a, 0));
 		unsigned gr = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, ((uint64_t)nb + 255) / 256);
-		hipLaunchKernelGGL((fwd_kernel<256>), dim3(gr), dim3(256), 0, e->stream2, R);
+		LAUNCH_CT(count, fwd_kernel, dim3(gr), e->stream2, R);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
 		return CS_OK;
@@ -677,10 +711,10 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 			unsigned gf = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * e->occ_fwd, (cn + 255) / 256);
 			if (iter == 0 && fwd0_on) { // the calls at the first base of each read: a kernel without LEPs, backward tasks, SST (smem_split.hpp)
 				unsigned g0 = (unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 8, (cn + 255) / 256);
-				hipLaunchKernelGGL((fwd0_kernel<256>), dim3(g0), dim3(256), 0, s, A, cur + c0);
+				LAUNCH_CT(count, fwd0_kernel, dim3(g0), s, A, cur + c0);
 				HIP_TRY(hipMemsetAsync(C, 0, sizeof(unsigned long long), s));
 			}
-			hipLaunchKernelGGL((fwd_kernel<256>), dim3(gf), dim3(256), 0, s, A);
+			LAUNCH_CT(count, fwd_kernel, dim3(gf), s, A);
 			HIP_TRY(hipGetLastError());
 			if (r3_async && !r3_launched && iter + 1 >= r3_after) { CS_TRY(launch_r3()); r3_launched = true; }
 			if (!r3_only) { // one launch works through all four size classes of the chunk's backward sweeps
@@ -689,19 +723,19 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
 				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
-				hipLaunchKernelGGL(bwd_wide_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
-				                   (const BTask *)e->d_bq.p, cn, C + 5);
+				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				                              (const BTask *)e->d_bq.p, cn, C + 5);
+				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				                        (const BTask *)e->d_bq.p, cn, C + 5);
 				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
 				if (A.win) { // the calls without stored LEPs, beside the others on a stream of their own
 					HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
-					hipLaunchKernelGGL((bwd_win0_kernel<256>), dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
-					                   (const BTask *)e->d_bq.p, cn);
+					LAUNCH_CT(count, bwd_win0_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), e->stream4, A,
+					          (const BTask *)e->d_bq.p, cn);
 					HIP_TRY(hipEventRecord(e->ev_wc, e->stream4));
 				}
-				if (A.win) hipLaunchKernelGGL((bwd_win_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), dim3(256), 0, s, A,
-				                              (const BTask *)e->d_bq.p, cn, C + 2);
-				else hipLaunchKernelGGL((bwd_all_kernel<256>), dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), dim3(256), 0, s, A,
-				                        (const BTask *)e->d_bq.p, cn, C + 2);
+				if (A.win) LAUNCH_CT(count, bwd_win_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), s, A, (const BTask *)e->d_bq.p, cn, C + 2);
+				else LAUNCH_CT(count, bwd_all_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), s, A, (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // all must be done before the slots and the LEP arena are reused
 				if (A.win) HIP_TRY(hipStreamWaitEvent(s, e->ev_wc, 0));
@@ -719,6 +753,9 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 		HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) return 1; // a queue or the overflow records ran full: the caller redoes the sub-batch with the fused kernel
+		// byte model, stream part: this iteration's queue words read (8 B), words pushed (8 B + 8 B side word), and per slot a
+		// backward task record cleared, written and scanned by three kernels (16 B each)
+		e->stream_bytes += n_f * (8 + 16 * 5) + H[1] * (r2text ? 16 + 16 + 8 : 16);
 		n_f = r2text ? H[16] : H[1];
 		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] iter %d: next queue %llu, sweeps created (last chunk) %llu, text sweeps so far %llu, reseed text %llu / index %llu\n", iter, H[1], H[13], H[14], H[11], H[12]);
 		HIP_TRY(hipMemsetAsync(C + 1, 0, sizeof(unsigned long long), s));
@@ -927,6 +964,9 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	HIP_TRY(hipStreamSynchronize(s));
 	CS_TRY(add_event_ms(e, e->ev[2], e->ev[3], &e->st.total_ms));
 	e->st.reads += (uint64_t)n_reads; e->st.bases += n_bases; e->st.mems += total_mems; e->st.seeds += *n_seeds_out;
+	// byte model, stream part: nt4 conversion reads and writes every base, the forward, backward and round-3 kernels each read
+	// it once more; a mem is written raw, read by the sort and written again (32 B each)
+	e->stream_bytes += n_bases * 5 + total_mems * 96;
 	return CS_OK;
 }
 
@@ -938,7 +978,9 @@ extern "C" int cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *pa
 	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
 	HIP_TRY(hipSetDevice(e->device));
 	uint64_t nm = 0, ns = 0;
+	e->last.valid = false;
 	CS_TRY(seed_device_impl(e, par, n_reads, d_bases, d_offsets, n_bases, &nm, &ns));
+	e->last.valid = true; e->last.n_reads = n_reads; e->last.n_mems = nm; e->last.n_seeds = ns; e->last.want_sal = par->want_sal;
 	out->n_reads = n_reads; out->n_mems = nm; out->n_seeds = ns;
 	out->mem_off = e->d_mem_off.p; out->mems = (const cs_intv_t *)e->d_mems.p;
 	out->seed_off = par->want_sal ? e->d_seed_off.p : nullptr;
@@ -964,7 +1006,9 @@ extern "C" int cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int6
 		HIP_TRY(hipMemcpyAsync(e->d_off.p, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
 	}
 	uint64_t nm = 0, ns = 0;
+	e->last.valid = false;
 	CS_TRY(seed_device_impl(e, par, n_reads, e->d_raw.p, e->d_off.p, n_bases, &nm, &ns));
+	e->last.valid = true; e->last.n_reads = n_reads; e->last.n_mems = nm; e->last.n_seeds = ns; e->last.want_sal = par->want_sal;
 	CS_TRY(e->h_mem_off.reserve((size_t)n_reads + 1));
 	CS_TRY(e->h_mems.reserve((size_t)nm + 1));
 	HIP_TRY(hipMemcpyAsync(e->h_mem_off.p, e->d_mem_off.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
@@ -980,6 +1024,106 @@ extern "C" int cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int6
 	out->mem_off = e->h_mem_off.p; out->mems = (const cs_intv_t *)e->h_mems.p;
 	out->seed_off = par->want_sal ? e->h_seed_off.p : nullptr;
 	out->seeds = par->want_sal ? (const cs_seed_t *)e->h_seeds.p : nullptr;
+	return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ digest / gather of the last result
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__global__ void digest_kernel(const uint64_t *w, uint64_t n, unsigned long long *out)
+{
+	unsigned long long acc = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		acc += splitmix64(w[i] + i * 0x9E3779B97F4A7C15ull);
+	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+extern "C" int cs_engine_result_digest(cs_engine_t *e, cs_digest_t *out)
+{
+	if (!e || !out) return fail(CS_EINVAL, "null argument");
+	if (!e->last.valid) return fail(CS_EINVAL, "cs_engine_result_digest: no result held (call a seed function first)");
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t s = e->stream;
+	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 4 * sizeof(unsigned long long), s));
+	const uint64_t n = (uint64_t)e->last.n_reads;
+	const unsigned g = (unsigned)e->n_cu * 8;
+	hipLaunchKernelGGL(digest_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_mem_off.p, n + 1, e->d_ctr.p + 0);
+	if (e->last.n_mems) hipLaunchKernelGGL(digest_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_mems.p, e->last.n_mems * 4, e->d_ctr.p + 1);
+	if (e->last.want_sal) {
+		hipLaunchKernelGGL(digest_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_seed_off.p, n + 1, e->d_ctr.p + 2);
+		if (e->last.n_seeds) hipLaunchKernelGGL(digest_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_seeds.p, e->last.n_seeds * 2, e->d_ctr.p + 3);
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	out->mem_off = e->h_ctr.p[0]; out->mems = e->h_ctr.p[1]; out->seed_off = e->h_ctr.p[2]; out->seeds = e->h_ctr.p[3];
+	return CS_OK;
+}
+
+__global__ void sel_counts_kernel(const uint64_t *ids, int64_t n_sel, uint64_t n_reads, const uint64_t *mem_off, const uint64_t *seed_off,
+                                  uint64_t *cm, uint64_t *cs, unsigned long long *bad)
+{
+	int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > n_sel) return;
+	if (t == n_sel) { cm[t] = 0; if (cs) cs[t] = 0; return; }
+	const uint64_t r = ids[t];
+	if (r >= n_reads) { atomicAdd(bad, 1ull); cm[t] = 0; if (cs) cs[t] = 0; return; }
+	cm[t] = mem_off[r + 1] - mem_off[r];
+	if (cs) cs[t] = seed_off[r + 1] - seed_off[r];
+}
+// 16 lanes per selected read copy its mems and seeds
+__global__ void sel_copy_kernel(const uint64_t *ids, int64_t n_sel, const uint64_t *mem_off, const uint64_t *seed_off, const OutMem *mems, const OutSeed *seeds,
+                                const uint64_t *om, const uint64_t *os, OutMem *out_m, OutSeed *out_s)
+{
+	const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+	const uint32_t a = threadIdx.x & 15u;
+	if (t >= n_sel) return;
+	const uint64_t r = ids[t];
+	for (uint64_t j = a, n = om[t + 1] - om[t]; j < n; j += 16) out_m[om[t] + j] = mems[mem_off[r] + j];
+	if (seeds) for (uint64_t j = a, n = os[t + 1] - os[t]; j < n; j += 16) out_s[os[t] + j] = seeds[seed_off[r] + j];
+}
+extern "C" int cs_engine_gather_reads(cs_engine_t *e, int64_t n_sel, const uint64_t *read_ids, cs_result_t *out)
+{
+	if (!e || !out || n_sel < 0 || (n_sel > 0 && !read_ids)) return fail(CS_EINVAL, "cs_engine_gather_reads: bad argument");
+	if (!e->last.valid) return fail(CS_EINVAL, "cs_engine_gather_reads: no result held (call a seed function first)");
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t s = e->stream;
+	const bool sal = e->last.want_sal != 0;
+	CS_TRY(e->d_sel.reserve((size_t)n_sel + 1)); CS_TRY(e->d_sel_moff.reserve((size_t)n_sel + 2)); CS_TRY(e->d_sel_soff.reserve((size_t)n_sel + 2));
+	CS_TRY(e->d_tmp.reserve(((size_t)n_sel + 2) * 16 + 1024));
+	uint64_t *cm = (uint64_t *)e->d_tmp.p, *cs = cm + n_sel + 1;
+	if (n_sel) HIP_TRY(hipMemcpyAsync(e->d_sel.p, read_ids, (size_t)n_sel * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(hipMemsetAsync(e->d_ctr.p + 4, 0, sizeof(unsigned long long), s));
+	hipLaunchKernelGGL(sel_counts_kernel, dim3(grid_for(n_sel + 1, 256)), dim3(256), 0, s, (const uint64_t *)e->d_sel.p, n_sel, (uint64_t)e->last.n_reads,
+	                   (const uint64_t *)e->d_mem_off.p, sal ? (const uint64_t *)e->d_seed_off.p : nullptr, cm, sal ? cs : nullptr, e->d_ctr.p + 4);
+	{
+		size_t tb = 0;
+		HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cm, e->d_sel_moff.p, (uint64_t)0, (size_t)n_sel + 1, rocprim::plus<uint64_t>(), s));
+		CS_TRY(e->d_tmp2.reserve(tb + 16));
+		HIP_TRY(rocprim::exclusive_scan((void *)e->d_tmp2.p, tb, cm, e->d_sel_moff.p, (uint64_t)0, (size_t)n_sel + 1, rocprim::plus<uint64_t>(), s));
+		if (sal) HIP_TRY(rocprim::exclusive_scan((void *)e->d_tmp2.p, tb, cs, e->d_sel_soff.p, (uint64_t)0, (size_t)n_sel + 1, rocprim::plus<uint64_t>(), s));
+	}
+	CS_TRY(e->h_mem_off.reserve((size_t)n_sel + 1));
+	HIP_TRY(hipMemcpyAsync(e->h_mem_off.p, e->d_sel_moff.p, ((size_t)n_sel + 1) * 8, hipMemcpyDeviceToHost, s));
+	if (sal) { CS_TRY(e->h_seed_off.reserve((size_t)n_sel + 1)); HIP_TRY(hipMemcpyAsync(e->h_seed_off.p, e->d_sel_soff.p, ((size_t)n_sel + 1) * 8, hipMemcpyDeviceToHost, s)); }
+	HIP_TRY(hipMemcpyAsync(e->h_ctr.p + 4, e->d_ctr.p + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (e->h_ctr.p[4]) return fail(CS_EINVAL, "cs_engine_gather_reads: read id out of range");
+	const uint64_t nm = e->h_mem_off.p[n_sel], ns = sal ? e->h_seed_off.p[n_sel] : 0;
+	CS_TRY(e->d_sel_mems.reserve((size_t)nm + 1)); CS_TRY(e->h_mems.reserve((size_t)nm + 1));
+	if (sal) { CS_TRY(e->d_sel_seeds.reserve((size_t)ns + 1)); CS_TRY(e->h_seeds.reserve((size_t)ns + 1)); }
+	if (n_sel) hipLaunchKernelGGL(sel_copy_kernel, dim3(grid_for(n_sel * 16, 256)), dim3(256), 0, s, (const uint64_t *)e->d_sel.p, n_sel, (const uint64_t *)e->d_mem_off.p,
+	                              (const uint64_t *)e->d_seed_off.p, (const OutMem *)e->d_mems.p, sal ? (const OutSeed *)e->d_seeds.p : nullptr,
+	                              (const uint64_t *)e->d_sel_moff.p, (const uint64_t *)e->d_sel_soff.p, e->d_sel_mems.p, e->d_sel_seeds.p);
+	HIP_TRY(hipGetLastError());
+	if (nm) HIP_TRY(hipMemcpyAsync(e->h_mems.p, e->d_sel_mems.p, (size_t)nm * sizeof(OutMem), hipMemcpyDeviceToHost, s));
+	if (ns) HIP_TRY(hipMemcpyAsync(e->h_seeds.p, e->d_sel_seeds.p, (size_t)ns * sizeof(OutSeed), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	out->n_reads = n_sel; out->n_mems = nm; out->n_seeds = ns;
+	out->mem_off = e->h_mem_off.p; out->mems = (const cs_intv_t *)e->h_mems.p;
+	out->seed_off = sal ? e->h_seed_off.p : nullptr; out->seeds = sal ? (const cs_seed_t *)e->h_seeds.p : nullptr;
 	return CS_OK;
 }
 

@@ -46,6 +46,42 @@ struct DevIndex {
 	const uint8_t *rep;
 };
 
+// ---- byte model of the kernels (bench.py's roofline): every read of an index-side array is an EVENT, counted per lane in a
+// register and summed over the wave once, at the end of the kernel, into evc[kernel][event] (no atomics in the hot loop).
+// The engine turns events into bytes (cs_engine_traffic_model).
+enum : int { EV_REC = 0 /* 32-B Occ record */, EV_JUMP /* 16-B jump-table entry */, EV_BLOOM /* 8-B filter word */, EV_SA /* full-SA entry */,
+             EV_ISA /* inverse-SA entry */, EV_TEXT /* 4-B word of the 2-bit text */, EV_REP /* 8-B load of rep[] */, EV_LCP /* byte of lcp[] */,
+             EV_LEP /* 16-B LEP entry read or written */, EV_MEM /* 32-B mem record read back */, N_EV };
+enum : int { KID_FWD0 = 0, KID_FWD, KID_BWD_WIN, KID_BWD_WIN0, KID_BWD_WIDE, KID_BWD_ALL, KID_R2TEXT, KID_R3TEXT, KID_FUSED, N_KID };
+// The counters cost registers the hot kernels do not have to spare (their launch bounds leave no slack: the counting build of
+// fwd_kernel spills dozens of VGPRs instead of 9), so the kernels exist twice: WaveCtrT<false> compiles to nothing and is what
+// every timed call runs; cs_params_t.count_traffic selects the counting instantiation for a pass whose only purpose is the model.
+template <bool ON> struct WaveCtrT;
+template <> struct WaveCtrT<true> {
+	uint32_t v[N_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                               // this LANE's events
+	__device__ __forceinline__ void add(int ev, uint32_t n) { v[ev] += n; }
+	__device__ __forceinline__ void addn(int ev, uint32_t n) { v[ev] += n; }
+	__device__ __forceinline__ void rec(bool two) { v[EV_REC] += two ? 2u : 1u; }
+	__device__ __forceinline__ void flush(unsigned long long *evc, int kid) const                    // every lane of the wave must call it
+	{
+		for (int ev = 0; ev < N_EV; ++ev) {
+			unsigned long long t = v[ev];
+			for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+			if ((threadIdx.x & 63u) == 0 && evc && t) atomicAdd(evc + kid * N_EV + ev, t);
+		}
+	}
+};
+template <> struct WaveCtrT<false> {
+	__device__ __forceinline__ void add(int, uint32_t) {}
+	__device__ __forceinline__ void addn(int, uint32_t) {}
+	__device__ __forceinline__ void rec(bool) {}
+	__device__ __forceinline__ void flush(unsigned long long *, int) const {}
+};
+using WaveCtr = WaveCtrT<true>;
+using NoCtr = WaveCtrT<false>;
+template <class WC> __device__ __forceinline__ void wc_add(WC &W, int ev, uint32_t per_lane = 1u) { W.add(ev, per_lane); }
+template <class WC> __device__ __forceinline__ void wc_flush(const WC &W, unsigned long long *evc, int kid) { W.flush(evc, kid); }
+
 struct Intv { uint64_t x0, x1; uint32_t x2; }; // the search's bi-interval; x2 < 2^32: no base occurs 2^32 times (checked at upload)
 struct Intv64 { uint64_t x0, x1, x2; };           // the primitive entry points take any interval, e.g. the whole text
 
@@ -173,8 +209,8 @@ __device__ __forceinline__ int extend4(const DevIndex &ix, const Intv64 &ik, boo
 // searched coordinate are primary-adjusted and fetched before anything is counted, so the two lines travel together.
 // The searched coordinate is never 0 for a real bi-interval (it starts at L2[c]+1 >= 1), so the k == -1 sentinel of
 // bwt_2occ4 cannot occur here; the four-child form above keeps it for the primitive-level entry points.
-template <bool IS_BACK>
-__device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int c)
+template <bool IS_BACK, class WC>
+__device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int c, WC &W)
 {
 	uint64_t xa = IS_BACK ? ik.x0 : ik.x1, xb = IS_BACK ? ik.x1 : ik.x0;
 	uint64_t k = xa - 1, l = xa - 1 + ik.x2;
@@ -183,6 +219,7 @@ __device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int 
 	// two.  The second load sits under the lane's predicate and is issued right behind the first, so when it is needed the
 	// two still travel together; nothing waits until the first use below.
 	const bool two = (rk >> OCC_SHIFT) != (rl >> OCC_SHIFT);
+	W.rec(two); // records requested: one per lane, two where the rows straddle
 	Block bk = load_block(ix, rk >> OCC_SHIFT);
 	Block b2;
 	if (two) b2 = load_block(ix, rl >> OCC_SHIFT);
@@ -214,11 +251,12 @@ __device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int 
 
 // direction chosen at run time (the fused single-kernel path): forward extension is backward extension with the two
 // coordinates swapped (bwt.c:265-274 is symmetric in x[!is_back] / x[is_back])
-__device__ __forceinline__ Intv extend1_rt(const DevIndex &ix, const Intv &ik, bool is_back, int c)
+template <class WC>
+__device__ __forceinline__ Intv extend1_rt(const DevIndex &ix, const Intv &ik, bool is_back, int c, WC &W)
 {
 	Intv s;
 	s.x0 = is_back ? ik.x0 : ik.x1; s.x1 = is_back ? ik.x1 : ik.x0; s.x2 = ik.x2;
-	Intv y = extend1<true>(ix, s, c), o;
+	Intv y = extend1<true>(ix, s, c, W), o;
 	o.x0 = is_back ? y.x0 : y.x1; o.x1 = is_back ? y.x1 : y.x0; o.x2 = y.x2;
 	return o;
 }

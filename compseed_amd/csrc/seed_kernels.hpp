@@ -43,6 +43,7 @@ struct SeedArgs {
 	uint4    *spill;            // [grid threads][spill_cap] LEP entries beyond the LDS part
 	uint32_t  spill_cap;
 	unsigned long long *n_queries; // device counter: bwt_extend queries issued
+	unsigned long long *evc;       // byte-model event counters [N_KID][N_EV] (fm_device.hpp), or null
 };
 
 enum : int {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void unpack_lep(const uint4 &e, Intv &v, uint32_t &en
 	end = e.w >> 16;
 }
 
-template <int BLOCK, int LEP_LDS>
+template <int BLOCK, int LEP_LDS, bool COUNT>
 __global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2)) void smem_kernel(const SeedArgs A)
 {
 	__shared__ uint4 lds_lep[LEP_LDS * BLOCK];
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2))
 	int r2_k = 0, r2_n = 0;
 	uint64_t win = 0; uint32_t win_key = 0xffffffffu; // 8-base window of the read
 	unsigned long long my_queries = 0;
+	WaveCtrT<COUNT> W;
 	OutMem *my_out = nullptr;
 
 	auto qbase = [&](int pos) -> uint32_t {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2))
 
 		// ---------------------------------------------------------------- the one extension site
 		Intv src = is_back ? pj : ik;
-		Intv y = extend1_rt(ix, src, is_back, c);
+		Intv y = extend1_rt(ix, src, is_back, c, W);
 		++my_queries;
 
 		// ---------------------------------------------------------------- consume
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(BLOCK, (LEP_LDS <= 10 ? 4 : LEP_LDS <= 13 ? 3 : 2))
 		}
 	}
 	if (A.n_queries) atomicAdd(A.n_queries, my_queries);
+	wc_flush(W, A.evc, KID_FUSED);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -350,8 +353,9 @@ __global__ void extend_kernel(const DevIndex ix, const OutMem *ik, const uint8_t
 		OutMem m = {o[c].x0, o[c].x1, o[c].x2, 0};
 		ok[4 * t + c] = m;
 		// the single-child paths used by the search must agree with the four-child one
-		Intv o1 = extend1_rt(ix, v, is_back[t] != 0, c);
-		Intv o2 = is_back[t] ? extend1<true>(ix, v, c) : extend1<false>(ix, v, c);
+		NoCtr W;
+		Intv o1 = extend1_rt(ix, v, is_back[t] != 0, c, W);
+		Intv o2 = is_back[t] ? extend1<true>(ix, v, c, W) : extend1<false>(ix, v, c, W);
 		if (small && v.x0 != 0 && v.x1 != 0 && (o2.x0 != o[c].x0 || o2.x1 != o[c].x1 || o2.x2 != o[c].x2)) ok[4 * t + c].info = 2;
 		if (small && (o1.x0 != o[c].x0 || o1.x1 != o[c].x1 || o1.x2 != o[c].x2)) ok[4 * t + c].info = 1;
 	}

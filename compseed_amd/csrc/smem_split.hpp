@@ -72,6 +72,7 @@ struct SplitArgs {
 	int32_t   sst;                                    // cs_params_t.sst_mode
 	uint4    *sst2;                                   // second SST level (global, SST2_ENTRIES)
 	const uint4 *jump; int32_t jump_k;                // round-3 jump table: bi-interval of every jump_k-mer (or null)
+	unsigned long long *evc;                          // byte-model event counters [N_KID][N_EV] (fm_device.hpp), or null
 };
 
 __device__ __forceinline__ void emit_mem(const SplitArgs &A, uint32_t r, const Intv &v, uint32_t beg, uint32_t end)
@@ -166,7 +167,8 @@ __global__ void jump_fill_kernel(const DevIndex ix, int k, uint4 *table)
 	uint64_t n = 1ull << (2 * k);
 	for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < n; m += (uint64_t)gridDim.x * blockDim.x) {
 		Intv v = set_intv(ix, (int)((m >> (2 * (k - 1))) & 3));
-		for (int j = k - 2; j >= 0; --j) v = extend1<false>(ix, v, 3 - (int)((m >> (2 * j)) & 3));
+		NoCtr W;
+		for (int j = k - 2; j >= 0; --j) v = extend1<false>(ix, v, 3 - (int)((m >> (2 * j)) & 3), W);
 		table[m] = pack_lep(v, 0);
 	}
 }
@@ -350,7 +352,7 @@ __device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r,
 	return x < len ? ftask_pack(r, (uint32_t)x, 1u + d, TK_ROUND1) : FTASK_NONE;
 }
 
-template <int BLOCK>
+template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 {
 	const DevIndex &ix = A.ix;
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 	uint32_t my_q = 0, my_hits = 0, my_sw = 0; // per-lane counters (a lane sees a few thousand extensions at most); bit 31 of my_sw: created a backward task
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
+	WaveCtrT<COUNT> W;
 	__shared__ uint4 sst[SST_ENTRIES];
 	sst_clear(sst);
 	const bool use_sst = A.sst != 0;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 			uint32_t code = 0; bool clean = true;
 			for (int q = 0; q < jump_k; ++q) { uint32_t bq = rd.at(x + q); clean = clean && bq <= 3; code = code << 2 | (bq & 3); }
 			if (clean) {
-				uint32_t e; unpack_lep(A.jump[code], ik, e);
+				uint32_t e; unpack_lep(A.jump[code], ik, e); wc_add(W, EV_JUMP);
 				i = x + jump_k; slen = jump_k; scode = 0;
 				my_q += (unsigned)(jump_k - 1); my_hits += (unsigned)(jump_k - 1);
 				return true;
@@ -440,11 +443,12 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 					uint32_t tb = tpos < ix.seq_len ? (tw >> ((uint32_t)(tpos & 15) << 1)) & 3u : 4u;
 					if (tb != b) { fin = true; break; }                    // mismatch or text end: that extension returns size 0
 					++i; ++tpos;
-					if ((tpos & 15) == 0) tw = ix.text2[tpos >> 4];        // padded: readable up to and including seq_len
+					if ((tpos & 15) == 0) { tw = ix.text2[tpos >> 4]; wc_add(W, EV_TEXT); } // padded: readable up to and including seq_len
 				}
 				ik.x1 = tpos;
 				if (fin) {
 					ik.x1 = isa_direct(ix, ix.seq_len - tpos); kind = TK_ROUND1; // rank of the reverse complement of [x, i)
+					wc_add(W, EV_ISA);
 					// The sweep of this call cannot pass the previous pivot x - dprev (chain_round1), and while the unique
 					// match keeps agreeing with the text in front of it, it stays the longest survivor and nothing else is
 					// reported (bwt.c:328-336).  So if the dprev - 1 bases between the pivots agree, the whole sweep reports
@@ -454,12 +458,13 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 						const uint64_t px = tpos - (uint64_t)(i - x); // text position of read base x
 						bool same = px >= (uint64_t)nb;
 						const uint64_t rbase = A.off[r];
+						wc_add(W, EV_TEXT, 2u); // (the dprev - 1 bases in front of the pivot: one or two words of the text)
 						for (int q = 1; same && q <= nb; ++q) {
 							uint64_t tp = px - (uint64_t)q;
 							same = ((ix.text2[tp >> 4] >> ((uint32_t)(tp & 15) << 1)) & 3u) == (uint32_t)A.seq[rbase + (uint64_t)(x - q)];
 						}
 						if (same) {
-							Intv m = {isa_direct(ix, px - (uint64_t)nb), ik.x1, 1};
+							Intv m = {isa_direct(ix, px - (uint64_t)nb), ik.x1, 1}; wc_add(W, EV_ISA);
 							push0 = emit_smem(A, r, TK_ROUND1, m, x - nb, (uint32_t)i, aux0);
 							push1 = chain_round1(A, r, i, x);
 							++my_sw; active = false; fin = false;
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 				if (b <= 3) {
 					++my_q;
 					if (cached) ++my_hits;
-					else { y = extend1<false>(ix, ik, 3 - (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
+					else { y = extend1<false>(ix, ik, 3 - (int)b, W); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
 					scode = ccode; ++slen;                          // slen keeps counting; only values < SST2_K are looked at
 				}
 				if (kind == TK_ROUND3) { // bwt_seed_strategy1, bwt.c:366-377
@@ -491,12 +496,13 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 				} else { // ---- forward pass of an SMEM call, bwt.c:303-320
 					const bool changed = b > 3 || y.x2 != ik.x2;            // read end (i == len), ambiguous base, or size change
 					fin = b > 3 || (y.x2 != ik.x2 && y.x2 < min_intv);
-					if (changed && !fin && x != 0 && (!A.win || i - x >= A.min_seed_len)) lep[n++] = pack_lep(ik, (uint32_t)i);
+					if (changed && !fin && x != 0 && (!A.win || i - x >= A.min_seed_len)) { lep[n++] = pack_lep(ik, (uint32_t)i); wc_add(W, EV_LEP); }
 					if (!fin) {
 						ik = y; ++i;
 						if (text_on && ik.x2 == 1 && kind == TK_ROUND1) { // unique from here on: continue on the text
 							const uint64_t tp = sa_direct(ix, ik.x0) + (uint64_t)(i - x); // text cursor: the base that has to equal read base i
-							if (tp <= ix.seq_len) { kind = TK_TEXT; ik.x1 = tp; tw = ix.text2[tp >> 4]; }  // (always: the match lies inside the text)
+							wc_add(W, EV_SA);
+							if (tp <= ix.seq_len) { kind = TK_TEXT; ik.x1 = tp; tw = ix.text2[tp >> 4]; wc_add(W, EV_TEXT); }  // (always: the match lies inside the text)
 						}
 					}
 				}
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i, aux0);
 					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i, x);
 				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
-					if (!A.win || i - x >= A.min_seed_len) lep[n++] = pack_lep(ik, (uint32_t)i);
+					if (!A.win || i - x >= A.min_seed_len) { lep[n++] = pack_lep(ik, (uint32_t)i); wc_add(W, EV_LEP); }
 					uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
 					if (A.win) cls = n == 0 ? 6u : n <= WIN_G32_LEPS ? 4u : n <= WIN_G64_LEPS ? 5u : 3u;
 					BTask bt = {r, (uint16_t)x, (uint16_t)(min_intv | kind << 14), (uint16_t)n, (uint16_t)i, cls};
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 	if (my_hits) atomicAdd(A.n_sst_hits, (unsigned long long)my_hits);
 	if (my_sw & 0x80000000u) atomicAdd(A.n_btasks, 1ull);
 	if (my_sw & 0x7fffffffu) atomicAdd(A.n_text_sweeps, (unsigned long long)(my_sw & 0x7fffffffu));
+	wc_flush(W, A.evc, KID_FWD);
 }
 
 
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 // fwd_kernel (the calls are latency-bound, so resident waves are what counts).  It takes the calls it can start from the
 // jump table and replaces them by no-ops in the queue; whatever is left (reads that begin with an ambiguous base, are
 // shorter than jump_k, or whose first jump_k-mer does not occur) is fwd_kernel's, launched over the same queue afterwards.
-template <int BLOCK>
+template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint64_t *fq)
 {
 	const DevIndex &ix = A.ix;
@@ -548,6 +555,7 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 	uint32_t my_q = 0, my_hits = 0;
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
+	WaveCtrT<COUNT> W;
 	for (;;) {
 		uint64_t t_id = 0;
 		bool got = pool_take<256>(P, !active, A.task_ctr, A.n_f, t_id);
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 				const uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
 				if (len >= jk) {
 					uint32_t bad; const uint32_t code = kmer_code(A.seq, rb, jk, bad);
-					uint32_t e; unpack_lep(A.jump[code], ik, e);
+					uint32_t e; unpack_lep(A.jump[code], ik, e); wc_add(W, EV_JUMP);
 					if (bad <= 3 && ik.x2 > 0) {
 						fq[t_id] = FTASK_NONE;                       // ours
 						i = jk; textm = false; active = true;
@@ -581,22 +589,23 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 					uint32_t tb = tpos < ix.seq_len ? (tw >> ((uint32_t)(tpos & 15) << 1)) & 3u : 4u;
 					if (tb != b) { fin = true; break; }
 					++i; ++tpos;
-					if ((tpos & 15) == 0) tw = ix.text2[tpos >> 4];
+					if ((tpos & 15) == 0) { tw = ix.text2[tpos >> 4]; wc_add(W, EV_TEXT); }
 				}
 				ik.x1 = tpos;
-				if (fin) ik.x1 = isa_direct(ix, ix.seq_len - tpos);
+				if (fin) { ik.x1 = isa_direct(ix, ix.seq_len - tpos); wc_add(W, EV_ISA); }
 			} else {
 				uint32_t b = i < len ? rd.at(i) : 4u;
 				if (b > 3) fin = true;
 				else {
 					++my_q;
-					const Intv y = extend1<false>(ix, ik, 3 - (int)b);
+					const Intv y = extend1<false>(ix, ik, 3 - (int)b, W);
 					if (y.x2 == 0) fin = true;                       // bwt.c:313-315 with min_intv = 1
 					else {
 						ik = y; ++i;
 						if (ik.x2 == 1) {
 							const uint64_t tp = sa_direct(ix, ik.x0) + (uint64_t)i;
-							if (tp <= ix.seq_len) { textm = true; ik.x1 = tp; tw = ix.text2[tp >> 4]; } // (always: the match lies inside the text)
+							wc_add(W, EV_SA);
+							if (tp <= ix.seq_len) { textm = true; ik.x1 = tp; tw = ix.text2[tp >> 4]; wc_add(W, EV_TEXT); } // (always: the match lies inside the text)
 						}
 					}
 				}
@@ -615,12 +624,13 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, (unsigned long long)my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, (unsigned long long)my_hits);
+	wc_flush(W, A.evc, KID_FWD0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int G>
+template <int G, class WC>
 __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
-                                               unsigned long long &my_q, unsigned long long &my_hits, uint4 *sst)
+                                               unsigned long long &my_q, unsigned long long &my_hits, uint4 *sst, WC &W)
 {
 	const bool use_sst = A.sst != 0;
 	int slen = SST2_K; uint32_t scode = 0; // this lane's match as a string, while it is short enough for the SST
@@ -672,7 +682,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				r = bt.r; kind = bt.mi_kind >> 14; min_intv = bt.mi_kind & 0x3fffu; ret = bt.ret;
 				int x = bt.x, n = bt.n; xp = x;
 				live = (int)gl < n;
-				if (live) unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend);
+				if (live) { unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend); wc_add(W, EV_LEP); }
 				uint64_t rb = A.off[r];
 				rd.start(A.seq, rb, x - 1);
 				i = x - 1; nm = 0; last_start = 0;
@@ -702,7 +712,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				if (live) {
 					++my_q;
 					if (cached) ++my_hits;
-					else { y = extend1<true>(ix, e, (int)b); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
+					else { y = extend1<true>(ix, e, (int)b, W); if (cacheable) sst_put(sst, A.sst2, slen + 1, ccode, y); }
 					if (slen < SST2_K) { scode = ccode; ++slen; }
 				}
 				bool stop = live && y.x2 < min_intv, cand = live && !stop;
@@ -752,8 +762,9 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 // replace 136 extensions, 17 deep; results identical.
 //
 // A group of G lanes per call: lanes 0..17 take the ends x+1 .. x+18, lanes 18.. take the stored LEPs in ascending order.
+template <class WC>
 __device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, uint64_t rb, int x, int ret, uint32_t min_intv,
-                                              Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits)
+                                              Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits, WC &W)
 {
 	const int k = A.min_seed_len, jk = A.jump_k;
 	const int te = x + 1 + (int)gl;
@@ -761,21 +772,22 @@ __device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, u
 	if (A.bloom) { // does the min_seed_len-mer [te - k, te) occur at all?
 		uint32_t badk;
 		const uint64_t ck = kmer_code_lsb(A.seq, rb + (uint64_t)(te - k), k, badk);
+		wc_add(W, EV_BLOOM);
 		if (badk > 3 || !kmer_filter_has(A.bloom, A.bloom_bits, ck)) return false;
 	}
 	uint32_t bad;
 	const uint32_t code = kmer_code(A.seq, rb + (uint64_t)(te - jk), jk, bad);
 	if (bad > 3) return false; // an ambiguous base inside the window: this end cannot reach min_seed_len
-	uint32_t dummy; unpack_lep(A.jump[code], e, dummy);
+	uint32_t dummy; unpack_lep(A.jump[code], e, dummy); wc_add(W, EV_JUMP);
 	my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
 	if (e.x2 < min_intv) return false;
 	pend = (uint32_t)te; s = te - jk - 1;
 	return true;
 }
 
-template <int G>
+template <int G, class WC>
 __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
-                                            unsigned long long &my_q, unsigned long long &my_hits)
+                                            unsigned long long &my_q, unsigned long long &my_hits, WC &W)
 {
 	constexpr uint32_t MYCLS = G == 32 ? 4u : 5u;
 	const DevIndex &ix = A.ix;
@@ -817,11 +829,11 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 				const int n = bt.n;
 				const uint64_t rb = A.off[r];
 				f = 0x7fffffff;
-				if (gl < (uint32_t)WIN_LANES) valid = win_lane_init(A, gl, rb, xp, ret, min_intv, e, pend, s, my_q, my_hits);
+				if (gl < (uint32_t)WIN_LANES) valid = win_lane_init(A, gl, rb, xp, ret, min_intv, e, pend, s, my_q, my_hits, W);
 				else {
 					int j = (int)gl - WIN_LANES;
 					valid = j < n;
-					if (valid) { unpack_lep(A.lep[(size_t)t * A.lep_stride + j], e, pend); s = xp - 1; }
+					if (valid) { unpack_lep(A.lep[(size_t)t * A.lep_stride + j], e, pend); s = xp - 1; wc_add(W, EV_LEP); }
 				}
 				walking = valid;
 				if (valid) rd.start(A.seq, rb, s);
@@ -843,7 +855,7 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 				uint32_t b = s < 0 ? 4u : rd.at(s);
 				if (b > 3) { f = s; walking = false; }
 				else {
-					Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+					Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
 					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
 				}
 			}
@@ -877,8 +889,9 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 // of the sweep streams the live part through the wave 64 entries at a time, longest first, compacting it in place (the
 // write index never passes below the chunk being processed).  Same rules as above; the "previous surviving size" is
 // carried from chunk to chunk.
+template <class WC>
 __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr, WaveOut &O,
-                                             unsigned long long &my_q)
+                                             unsigned long long &my_q, WC &W)
 {
 	const DevIndex &ix = A.ix;
 	const uint32_t lane = threadIdx.x & 63u;
@@ -909,9 +922,9 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 			for (int top = n; top > lo; top -= 64) {
 				int j = top - 1 - (int)lane; bool valid = j >= lo;
 				Intv p = {0, 0, 0}; uint32_t pend = 0;
-				if (valid) unpack_lep(lep[j], p, pend);
+				if (valid) { unpack_lep(lep[j], p, pend); wc_add(W, EV_LEP); }
 				Intv y = p;
-				if (valid && b <= 3) { y = extend1<true>(ix, p, (int)b); ++my_q; }
+				if (valid && b <= 3) { y = extend1<true>(ix, p, (int)b, W); ++my_q; }
 				bool cand = valid && b <= 3 && y.x2 >= min_intv;
 				uint64_t cand_m = __ballot(cand);
 				if (!first_done) { // lane 0 of the first chunk holds the longest live match (bwt.c:328-336)
@@ -927,7 +940,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 				if (!before) px2 = prev_carry;
 				bool keep = cand && ((!before && !have_prev) || y.x2 != px2); // bwt.c:337-340
 				uint64_t keep_m = __ballot(keep);
-				if (keep) lep[w - 1 - __popcll(keep_m & lt_mask)] = pack_lep(y, pend);
+				if (keep) { lep[w - 1 - __popcll(keep_m & lt_mask)] = pack_lep(y, pend); wc_add(W, EV_LEP); }
 				w -= __popcll(keep_m);
 				if (cand_m) { have_prev = true; prev_carry = __shfl(y.x2, 63 - __clzll((long long)cand_m)); }
 			}
@@ -941,14 +954,14 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 			// settled here by lanes 0..17 (bwd_win_run), the nearest longer end of the longest of them being the list above
 			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0, f = 0x7fffffff;
 			unsigned long long hits = 0;
-			bool valid = lane < (uint32_t)WIN_LANES && win_lane_init(A, lane, rb, (int)bt.x, (int)bt.ret, min_intv, e, pend, s, my_q, hits);
+			bool valid = lane < (uint32_t)WIN_LANES && win_lane_init(A, lane, rb, (int)bt.x, (int)bt.ret, min_intv, e, pend, s, my_q, hits, W);
 			bool walking = valid;
 			while (__ballot(walking)) {
 				if (walking) {
 					uint32_t b = s < 0 ? 4u : A.seq[rb + (uint64_t)s];
 					if (b > 3) { f = s; walking = false; }
 					else {
-						Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+						Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
 						if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
 					}
 				}
@@ -971,7 +984,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 // starting with a different one depending on its workgroup, so all classes progress at once and a wave whose class runs
 // dry moves on to the next instead of idling through that class's tail.  The three orders are written out (a loop over a
 // class index costs 35 more VGPRs and one wave per SIMD).  ctrs[c] is the slot counter of class c.
-template <int BLOCK>
+template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
 	if (*A.n_btasks == 0) return; // e.g. the first launch of a batch: every call sits at pivot 0 and needs no sweep
@@ -979,23 +992,25 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 	unsigned long long my_q = 0, my_hits = 0;
 	__shared__ uint4 sst[SST_ENTRIES];
 	sst_clear(sst);
+	WaveCtrT<COUNT> W;
 	const uint32_t role = blockIdx.x & 7u; // 5/8 of the workgroups start on the <=16 class, 2/8 on <=32, 1/8 on <=64
 	if (role < 5) {
-		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
-		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
-		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
+		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst, W);
+		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst, W);
+		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst, W);
 	} else if (role < 7) {
-		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
-		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
-		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
+		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst, W);
+		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst, W);
+		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst, W);
 	} else {
-		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst);
-		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst);
-		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst);
+		bwd_groups_run<64>(A, bq, n_tasks, ctrs + 2, O, my_q, my_hits, sst, W);
+		bwd_groups_run<16>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, sst, W);
+		bwd_groups_run<32>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, sst, W);
 	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+	wc_flush(W, A.evc, KID_BWD_ALL);
 }
 
 // Calls without any stored LEP (the forward match is shorter than min_seed_len: typically the call at a mismatch, whose
@@ -1008,7 +1023,7 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 // them inside their round kept the whole wave waiting for one or two lanes a third of the time; the kernel is VALU-bound.)
 // No dispenser and no atomics on the task side.
 struct WinPark { uint4 iv; int32_t s; uint32_t r; uint16_t mk; uint8_t key, g; uint32_t pad; }; // 32 B: a match that reached min_seed_len
-template <int BLOCK>
+template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
 {
 	if (*A.n_btasks == 0) return;
@@ -1021,6 +1036,7 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 	const uint32_t seg = lane / WIN_LANES, gl = lane - seg * WIN_LANES;      // three segments of 18 lanes; lanes 54..63 idle
 	const int kx = A.min_seed_len - A.jump_k;                                // extensions from the jump_k-mer to min_seed_len
 	WaveOut O = {0, 0};
+	WaveCtrT<COUNT> W;
 	unsigned long long my_q = 0, my_hits = 0;
 	int npark = 0; // wave-uniform
 	// walk the parked matches to their ends and report (bwd_win_run's rule, the lanes of a call found by their key)
@@ -1039,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 				uint32_t b = s < 0 ? 4u : (uint32_t)A.seq[rb + (uint64_t)s];
 				if (b > 3) { f = s; walking = false; }
 				else {
-					Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+					Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
 					if (y.x2 < min_intv) { f = s; walking = false; } else { e = y; --s; }
 				}
 			}
@@ -1082,13 +1098,13 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 			const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
 			const uint64_t rb = job ? A.off[r] : 0;
 			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0;
-			bool alive = job && win_lane_init(A, gl, rb, x, ret, min_intv, e, pend, s, my_q, my_hits);
+			bool alive = job && win_lane_init(A, gl, rb, x, ret, min_intv, e, pend, s, my_q, my_hits, W);
 			for (int st = 0; st < kx; ++st) { // wave-uniform: the jump_k-mer grows to min_seed_len bases, or the lane drops out
 				if (alive) {
 					const uint32_t b = (uint32_t)A.seq[rb + (uint64_t)s];          // s >= 0: the window starts inside the read
 					if (b > 3) alive = false;
 					else {
-						Intv y = extend1<true>(ix, e, (int)b); ++my_q;
+						Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
 						if (y.x2 < min_intv) alive = false; else { e = y; --s; }
 					}
 				}
@@ -1110,36 +1126,42 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+	wc_flush(W, A.evc, KID_BWD_WIN0);
 }
 
 // window scheme: ctrs[0] / ctrs[1] are the slot counters of the classes with up to 14 / 46 stored LEPs
-template <int BLOCK>
+template <int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK, 6) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
 	if (*A.n_btasks == 0) return;
 	WaveOut O = {0, 0};
+	WaveCtrT<COUNT> W;
 	unsigned long long my_q = 0, my_hits = 0;
 	if ((blockIdx.x & 7u) != 7u) {
-		bwd_win_run<32>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits);
-		bwd_win_run<64>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits);
+		bwd_win_run<32>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, W);
+		bwd_win_run<64>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, W);
 	} else {
-		bwd_win_run<64>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits);
-		bwd_win_run<32>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits);
+		bwd_win_run<64>(A, bq, n_tasks, ctrs + 1, O, my_q, my_hits, W);
+		bwd_win_run<32>(A, bq, n_tasks, ctrs + 0, O, my_q, my_hits, W);
 	}
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
+	wc_flush(W, A.evc, KID_BWD_WIN);
 }
 
 // the calls with more than 64 LEPs, one wave each; rare, so it runs beside bwd_all_kernel on its own stream
+template <bool COUNT>
 __global__ __launch_bounds__(256) void bwd_wide_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr)
 {
 	if (*A.n_btasks == 0) return;
 	WaveOut O = {0, 0};
+	WaveCtrT<COUNT> W;
 	unsigned long long my_q = 0;
-	bwd_wide_run(A, bq, n_tasks, ctr, O, my_q);
+	bwd_wide_run(A, bq, n_tasks, ctr, O, my_q, W);
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
+	wc_flush(W, A.evc, KID_BWD_WIDE);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1160,28 +1182,35 @@ __global__ __launch_bounds__(256) void bwd_wide_kernel(const SplitArgs A, const 
 // This only holds while the substrings stay inside [beg, end), where read and text agree: if a candidate reaches either
 // end of the SMEM, a capped value (255) turns up, or an interval walk gets long, nothing is emitted and the call stays
 // in the queue for fwd_kernel / bwd_all_kernel.  So the result is the reference's either way; only the cost differs.
+// per-lane event counts of the text-side kernels, handed to the kernel's WaveCtr at the end
+struct LaneCtr { uint32_t sa, isa, rep, lcp, mem; };
+__device__ __forceinline__ void lc_flush(LaneCtr c, WaveCtr &W)
+{
+	W.addn(EV_SA, c.sa); W.addn(EV_ISA, c.isa); W.addn(EV_REP, c.rep); W.addn(EV_LCP, c.lcp); W.addn(EV_MEM, c.mem);
+}
 struct RepReader { // rep[] bytes around a moving text position, one aligned 8-byte load per 8 positions
-	const uint8_t *base; uint64_t wk, w;
+	const uint8_t *base; uint64_t wk, w; uint32_t loads;
 	__device__ __forceinline__ uint32_t at(uint64_t pos)
 	{
 		uint64_t k = pos >> 3;
-		if (k != wk) { wk = k; w = *reinterpret_cast<const uint64_t *>(base + (k << 3)); }
+		if (k != wk) { wk = k; w = *reinterpret_cast<const uint64_t *>(base + (k << 3)); ++loads; }
 		return (uint32_t)(w >> ((pos & 7) << 3)) & 0xffu;
 	}
 };
 // bi-interval of the repeated substring of length v at text position pos (v <= 254, so the capped lcp[] decides exactly)
-__device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out, int MAX_WALK = 48)
+__device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out, LaneCtr &C, int MAX_WALK = 48)
 {
 	if (v == 0 || pos + v > ix.seq_len) return false; // (cannot happen for a substring of a mem; a walk must never leave the arrays)
 	uint64_t lo = isa_direct(ix, pos), hi = lo, lo2 = isa_direct(ix, ix.seq_len - (pos + v));
 	int steps = 0;
-	while (lo > 0 && ix.lcp[lo] >= v) { --lo; if (++steps > MAX_WALK) return false; }
-	while (hi < ix.seq_len && ix.lcp[hi + 1] >= v) { ++hi; if (++steps > MAX_WALK) return false; }
-	while (lo2 > 0 && ix.lcp[lo2] >= v) { --lo2; if (++steps > 2 * MAX_WALK) return false; }
+	C.isa += 2; C.lcp += 3;
+	while (lo > 0 && ix.lcp[lo] >= v) { --lo; ++C.lcp; if (++steps > MAX_WALK) return false; }
+	while (hi < ix.seq_len && ix.lcp[hi + 1] >= v) { ++hi; ++C.lcp; if (++steps > MAX_WALK) return false; }
+	while (lo2 > 0 && ix.lcp[lo2] >= v) { --lo2; ++C.lcp; if (++steps > 2 * MAX_WALK) return false; }
 	out.x0 = lo; out.x1 = lo2; out.x2 = hi - lo + 1;
 	return true;
 }
-__device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint64_t x0, int beg, int end, int pivot)
+__device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint64_t x0, int beg, int end, int pivot, LaneCtr &C)
 {
 	const DevIndex &ix = A.ix;
 	const int len = end - beg, po = pivot - beg, k = A.min_seed_len;
@@ -1191,8 +1220,10 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 	// are clipped to the read end, and a match that is still alive at the first base is reported there.
 	const bool at_start = beg == 0, at_end = (uint64_t)end == A.off[r + 1] - A.off[r];
 	const uint64_t P = sa_direct(ix, x0); // text position of read base `beg`
+	++C.sa;
 	if (P >= ix.seq_len || P + (uint64_t)len > ix.seq_len) return false; // (an SMEM lies inside the text)
-	RepReader R = {ix.rep, ~0ull, 0};
+	RepReader R = {ix.rep, ~0ull, 0, 0};
+	struct Tally { RepReader &R; LaneCtr &C; __device__ ~Tally() { C.rep += R.loads; } } tally = {R, C};
 	constexpr int MAXC = 8;               // reported substrings per call; more (tandem arrays): leave it to the index
 	int co[MAXC], cv[MAXC], ne = 0;
 	auto eff = [&](int o, int &v) -> bool { // repeat length at offset o as far as it matters; false: the text cannot tell
@@ -1216,7 +1247,7 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 		--o; v = vp;
 	}
 	Intv ci[MAXC];
-	for (int j = 0; j < ne; ++j) if (!text_interval(ix, P + (uint64_t)co[j], (uint32_t)cv[j], ci[j], 192)) return false;
+	for (int j = 0; j < ne; ++j) if (!text_interval(ix, P + (uint64_t)co[j], (uint32_t)cv[j], ci[j], C, 192)) return false;
 	for (int j = 0; j < ne; ++j) emit_mem(A, r, ci[j], (uint32_t)(beg + co[j]), (uint32_t)(beg + co[j] + cv[j]));
 	return true;
 }
@@ -1228,6 +1259,7 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const ui
 	uint64_t n = *n_ptr; if (n > A.fq_cap) n = A.fq_cap;
 	const uint32_t lane = threadIdx.x & 63u;
 	unsigned long long done = 0, left = 0;
+	LaneCtr C = {0, 0, 0, 0, 0};
 	// a wave takes 256 consecutive slots at a time (one atomic on the output counter per 256 slots)
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
 	for (uint64_t t0 = wave * 256; t0 < n; t0 += n_waves * 256) { // wave-uniform
@@ -1240,7 +1272,7 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const ui
 				uint64_t a = aux[t];
 				uint32_t r = (uint32_t)task[j]; int pivot = (int)((task[j] >> 32) & 0xffffu);
 				int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
-				if (r2_by_text(A, r, a & ((1ull << 37) - 1ull), beg, end, pivot)) { task[j] = FTASK_NONE; ++done; } else ++left;
+				if (r2_by_text(A, r, a & ((1ull << 37) - 1ull), beg, end, pivot, C)) { task[j] = FTASK_NONE; ++done; } else ++left;
 			}
 			km[j] = __ballot(task[j] != FTASK_NONE);
 			total += (uint32_t)__popcll(km[j]);
@@ -1258,6 +1290,9 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const ui
 	}
 	for (int o = 32; o > 0; o >>= 1) { done += __shfl_xor(done, o); left += __shfl_xor(left, o); }
 	if (lane == 0) { if (done) atomicAdd(n_done, done); if (left) atomicAdd(n_left, left); }
+	WaveCtr W; // (these two kernels have registers to spare: they always count)
+	lc_flush(C, W);
+	wc_flush(W, A.evc, KID_R2TEXT);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1276,16 +1311,18 @@ __global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const ui
 // 1 + #{neighbours sharing >= L} occurrences, so L = 1 + the (max_intv - 1)-th largest shared length (or k1 if fewer than
 // that many neighbours share k1 bases).  At most max_intv - 1 bytes of lcp[] on either side: two cache lines instead of the
 // dozens of bwt_extend calls such a seed costs in a repeat.  False when a capped value (255) would decide.
-__device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int k1, uint32_t max_intv, int &L)
+__device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int k1, uint32_t max_intv, int &L, LaneCtr &C)
 {
 	if (max_intv < 2 || max_intv > 41) return false;
 	const uint32_t m = max_intv - 1;
 	if (p >= ix.seq_len) return false;
 	uint64_t up = isa_direct(ix, p), dn = up + 1;
 	uint32_t mu = ix.lcp[up], md = ix.lcp[dn], val = 0;
+	++C.isa; C.lcp += 2;
 	for (uint32_t t = 0; t < m; ++t) {
 		val = mu > md ? mu : md;
 		if (val < (uint32_t)k1) { L = k1; return true; }   // fewer than max_intv occurrences already at k1 bases
+		++C.lcp;
 		if (mu >= md) { if (up == 0) return false; --up; const uint32_t c = ix.lcp[up]; mu = c < mu ? c : mu; }
 		else { if (dn > ix.seq_len) return false; ++dn; const uint32_t c = ix.lcp[dn]; md = c < md ? c : md; }
 	}
@@ -1303,6 +1340,8 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 	const int k1 = A.min_seed_len + 1;
 	const int jk = (A.jump && A.jump_k <= A.min_seed_len) ? A.jump_k : 0;
 	unsigned long long my_q = 0, my_hits = 0, my_text = 0;
+	LaneCtr C = {0, 0, 0, 0, 0};
+	WaveCtr W;
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
 		const uint64_t rb = A.off[r]; const int len = (int)(A.off[r + 1] - rb);
 		const uint32_t nm0 = cnt_snap[r] < A.cap ? cnt_snap[r] : A.cap; // the mems of rounds 1 and 2 known to be complete
@@ -1315,8 +1354,9 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 				cb = ce = 0;
 				for (uint32_t a = 0; a < nm0; ++a) {
 					const uint64_t info = mine[a].info; const int mb = (int)(info >> 32), me = (int)(uint32_t)info;
+					++C.mem;
 					if (x >= mb && x + k1 <= me) { // any occurrence will do
-						cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0);
+						cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0); ++C.sa;
 						if (cp >= ix.seq_len || cp + (uint64_t)(me - mb) > ix.seq_len) cb = ce = 0; // (a mem lies inside the text)
 						break;
 					}
@@ -1332,6 +1372,7 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 					uint32_t vj[SPEC];
 #pragma unroll
 					for (int j = 0; j < SPEC; ++j) vj[j] = j < ns ? (uint32_t)ix.rep[p + (uint64_t)(j * k1)] : 255u;
+					C.rep += (uint32_t)ns; // (single bytes, one line apiece: counted like the 8-byte loads of r2text_kernel)
 					int nu = 0; // leading unique k1-mers
 #pragma unroll
 					for (int j = 0; j < SPEC; ++j) if (nu == j && vj[j] < (uint32_t)k1) nu = j + 1;
@@ -1342,6 +1383,7 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 							const uint64_t pj = p + (uint64_t)(j * k1);
 							a0[j] = j < nu ? isa_direct(ix, pj) : 0; a1[j] = j < nu ? isa_direct(ix, ix.seq_len - (pj + (uint64_t)k1)) : 0;
 						}
+						C.isa += 2u * (uint32_t)nu;
 						const uint32_t k0 = atomicAdd(&A.out_cnt[r], (uint32_t)nu);
 #pragma unroll
 						for (int j = 0; j < SPEC; ++j) {
@@ -1362,10 +1404,11 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 				}
 				const uint32_t v = ix.rep[p];
 				Intv iv = {0, 0, 0}; bool ok = false;
-				if (v < (uint32_t)k1) { iv.x0 = isa_direct(ix, p); iv.x1 = isa_direct(ix, ix.seq_len - (p + (uint64_t)k1)); iv.x2 = 1; ok = true; }
+				++C.rep;
+				if (v < (uint32_t)k1) { iv.x0 = isa_direct(ix, p); iv.x1 = isa_direct(ix, ix.seq_len - (p + (uint64_t)k1)); iv.x2 = 1; ok = true; C.isa += 2; }
 				int L = k1;
-				if (!ok && k1 < 255 && r3_text_len(ix, p, k1, (uint32_t)(A.max_mem_intv > 0xffffffffull ? 0xffffffffull : A.max_mem_intv), L) && x + L <= ce)
-					ok = text_interval(ix, p, (uint32_t)L, iv) && iv.x2 < A.max_mem_intv;
+				if (!ok && k1 < 255 && r3_text_len(ix, p, k1, (uint32_t)(A.max_mem_intv > 0xffffffffull ? 0xffffffffull : A.max_mem_intv), L, C) && x + L <= ce)
+					ok = text_interval(ix, p, (uint32_t)L, iv, C) && iv.x2 < A.max_mem_intv;
 				if (ok) {
 					emit_mem(A, (uint32_t)r, iv, (uint32_t)x, (uint32_t)(x + L));
 					my_q += (unsigned)(L - 1); my_hits += (unsigned)(L - 1); ++my_text;
@@ -1378,7 +1421,7 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 			if (jk && x + jk <= len) {
 				uint32_t code = 0, bad = 0;
 				for (int q = 0; q < jk; ++q) { uint32_t b = A.seq[rb + (uint64_t)(x + q)]; bad |= b; code = code << 2 | (b & 3u); }
-				if (bad <= 3) { uint32_t dummy; unpack_lep(A.jump[code], ik, dummy); i = x + jk; jumped = true; my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1); }
+				if (bad <= 3) { uint32_t dummy; unpack_lep(A.jump[code], ik, dummy); wc_add(W, EV_JUMP); i = x + jk; jumped = true; my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1); }
 			}
 			if (!jumped) { ik = set_intv(ix, (int)A.seq[rb + (uint64_t)x]); i = x + 1; }
 			int nx = len;
@@ -1390,7 +1433,7 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 				const uint32_t b = rd.at(i);
 				if (b > 3) { nx = i + 1; break; }
 				if (dead) { if (i - x >= A.min_seed_len) { nx = i + 1; break; } continue; }
-				const Intv y = extend1<false>(ix, ik, 3 - (int)b); ++my_q;
+				const Intv y = extend1<false>(ix, ik, 3 - (int)b, W); ++my_q;
 				if (y.x2 < A.max_mem_intv && i - x >= A.min_seed_len) { if (y.x2 > 0) emit_mem(A, (uint32_t)r, y, (uint32_t)x, (uint32_t)(i + 1)); nx = i + 1; break; }
 				ik = y; dead = y.x2 == 0;
 			}
@@ -1399,6 +1442,8 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 	}
 	for (int o = 32; o > 0; o >>= 1) { my_q += __shfl_xor(my_q, o); my_hits += __shfl_xor(my_hits, o); my_text += __shfl_xor(my_text, o); }
 	if ((threadIdx.x & 63u) == 0) { atomicAdd(A.n_queries, my_q); if (my_hits) atomicAdd(A.n_sst_hits, my_hits); if (my_text) atomicAdd(n_text_seeds, my_text); }
+	lc_flush(C, W);
+	wc_flush(W, A.evc, KID_R3TEXT);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

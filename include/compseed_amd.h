@@ -63,6 +63,8 @@ typedef struct {
 	                          * Results are identical either way; only speed and the bwt_calls counter differ */
 	uint32_t disable;        /* bit mask of CS_DISABLE_*: switch single exact shortcuts off for this call (A/B parity tests,
 	                          * profiling).  0 [default] = everything the engine was created with is used */
+	uint32_t count_traffic;  /* 1: run the instantiations of the SMEM kernels that count their index-side accesses
+	                          * (cs_engine_traffic_model); same results, a few per cent slower.  0 [default] */
 } cs_params_t;
 
 /* cs_params_t.disable: every mechanism below is exact; switching one off changes speed and counters only */
@@ -175,6 +177,30 @@ int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_read
                           const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
 int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                                  const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases, cs_result_t *out);
+
+/* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array
+ *      (sum over the array's 64-bit words w[i] of splitmix64(w[i] + i * 0x9E3779B97F4A7C15), mod 2^64), so that two runs over
+ *      10 M reads can be compared word for word without downloading 6 GB; and the CSR slice of selected reads (any order,
+ *      repeats allowed) gathered on the device into the engine's pinned host buffers (what cs_engine_seed_batch would
+ *      have returned for exactly those reads -- results do not depend on the batch a read travels in). */
+typedef struct { uint64_t mem_off, mems, seed_off, seeds; } cs_digest_t;
+int  cs_engine_result_digest(cs_engine_t *e, cs_digest_t *out);
+int  cs_engine_gather_reads(cs_engine_t *e, int64_t n_sel, const uint64_t *read_ids, cs_result_t *out);
+
+/* ---- byte model of the SMEM stage as THIS implementation runs it (bench.py's roofline): every access the kernels make to an
+ *      index-side array is counted on the device as an event of its kernel; bytes = events x event_bytes.  These are the bytes
+ *      the kernels ask for -- a lower bound of what has to come out of HBM/L2 for them -- not the bytes of the reference's
+ *      algorithm (most of whose bwt_extend calls are answered without the FM index here).  Accumulated like cs_stats_t. */
+#define CS_N_KERNELS 9   /* fwd0, fwd, bwd_win, bwd_win0, bwd_wide, bwd_all, r2text, r3text, fused (smem_kernel) */
+#define CS_N_EVENTS 10   /* Occ record 32 B, jump entry 16 B, filter word 8 B, SA entry, inverse-SA entry (4 or 8 B), text word 4 B,
+                            rep[] load 8 B, lcp[] byte, LEP entry 16 B (read or written), mem record read back 32 B */
+typedef struct {
+	uint64_t events[CS_N_KERNELS][CS_N_EVENTS];
+	uint64_t event_bytes[CS_N_EVENTS];
+	uint64_t stream_bytes;   /* modelled on the host per call: read bases (nt4 conversion + one pass per kernel family), task
+	                            queue words, backward task records, raw mems written, sorted and written again */
+} cs_traffic_t;
+int  cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out);
 
 int  cs_engine_stats(const cs_engine_t *e, cs_stats_t *st);
 void cs_engine_reset_stats(cs_engine_t *e);

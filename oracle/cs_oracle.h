@@ -68,6 +68,9 @@ int  cso_index_load(cso_index_t *idx, const char *prefix);
 int  cso_index_wrap(cso_index_t *idx, uint64_t primary, const uint64_t L2_1to4[4], const uint32_t *bwt, uint64_t bwt_size,
                     const uint64_t *sa, uint64_t n_sa, uint64_t sa_intv);
 void cso_index_free(cso_index_t *idx);
+/* cs_index_naive.c: FM-index of a forward-strand genome (codes 0..3) by a plain comparison sort of all suffixes; the same
+ * arrays bwaidx writes (index_main.c:257-325).  For CPU-side tests that generate their own genome.  0 on success. */
+int  cso_index_build(const uint8_t *fwd_nt4, uint64_t l_pac, int n_threads, cso_index_t *out);
 
 /* primitives (bwt.c:169, 189, 262, 107, 53, 86; bwt.h:82) */
 void     cso_occ4(const cso_index_t *idx, uint64_t k, uint64_t cnt[4]);

@@ -71,3 +71,52 @@ def load_pac_forward(prefix=PREFIX):
     body = raw[:-1]
     codes = np.stack([(body >> 6) & 3, (body >> 4) & 3, (body >> 2) & 3, body & 3], axis=1).reshape(-1)
     return codes[:l_pac].astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0]: "E. coli K-12 ref, 100k x 100bp synthetic reads" -- the plumbing set of SURVEY 8(d) / Appendix C.1.
+# No real genome is available offline, so it is a uniform-random genome of E. coli K-12's length; the recipe below is the
+# survey's (Python's `random` with a fixed seed: the same interpreter here and on the GPU box), and it reproduces the
+# reference counters BASELINE.md section 2 records (38,109,585 bwt_extend queries; 28,527,263 / 29,553,396 real calls for
+# the sorted / shuffled order; 569,493 SAL queries).  tests/golden/c1/config1.json holds those counters and digests of the
+# reference's complete output, written by make_golden.py from the real reference.
+C1_LEN, C1_READS, C1_READ_LEN, C1_SEED = 4641652, 100000, 100, 20240601
+
+
+def config1_dataset():
+    """-> (genome str, sorted reads [str], shuffled reads [str])"""
+    import random
+    rng = random.Random(C1_SEED)
+    ref = "".join(rng.choices("ACGT", k=C1_LEN))
+    comp = str.maketrans("ACGTN", "TGCAN")
+    pos = sorted(rng.randrange(0, C1_LEN - C1_READ_LEN) for _ in range(C1_READS))
+    reads = []
+    for p in pos:
+        r = list(ref[p:p + C1_READ_LEN])
+        for i in range(C1_READ_LEN):
+            if rng.random() < 0.01:
+                r[i] = rng.choice("ACGT")
+        r = "".join(r)
+        if rng.random() < 0.5:
+            r = r.translate(comp)[::-1]
+        reads.append(r)
+    shuf = list(reads)
+    rng.shuffle(shuf)
+    return ref, reads, shuf
+
+
+def codes_of(seq_str):
+    """ACGT string -> uint8 codes 0..3"""
+    lut = np.full(256, 4, np.uint8)
+    for ch, v in zip(b"ACGT", range(4)):
+        lut[ch] = v
+    return lut[np.frombuffer(seq_str.encode(), dtype=np.uint8)]
+
+
+def digest_result(mem_off, mems, seed_off, seeds_rbeg, seeds_qbeg, seeds_len):
+    """md5 per array of a CSR seeding result (little-endian bytes), the form config1.json pins"""
+    import hashlib
+    def h(a, dt):
+        return hashlib.md5(np.ascontiguousarray(a, dtype=dt).tobytes()).hexdigest()
+    return {"mem_off": h(mem_off, "<u8"), "mems": h(mems, "<u8"), "seed_off": h(seed_off, "<u8"),
+            "seed_rbeg": h(seeds_rbeg, "<i8"), "seed_qbeg": h(seeds_qbeg, "<i4"), "seed_len": h(seeds_len, "<i4")}

@@ -49,13 +49,14 @@ def lib():
     if _lib is None:
         src_newer = (not os.path.exists(LIB_PATH) or
                      any(os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
-                         for f in ("cs_oracle.c", "cs_oracle.h")))
+                         for f in ("cs_oracle.c", "cs_oracle.h", "cs_index_naive.c")))
         if src_newer:
             subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, capture_output=True)
         L = C.CDLL(LIB_PATH)
         L.cso_index_load.argtypes = [C.POINTER(Index), C.c_char_p]
         L.cso_index_wrap.argtypes = [C.POINTER(Index), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64]
         L.cso_index_free.argtypes = [C.POINTER(Index)]
+        L.cso_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Index)]
         L.cso_occ4.argtypes = [C.POINTER(Index), C.c_uint64, C.POINTER(C.c_uint64)]
         L.cso_2occ4.argtypes = [C.POINTER(Index), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.cso_extend.argtypes = [C.POINTER(Index), C.POINTER(Intv), C.POINTER(Intv), C.c_int]
@@ -96,6 +97,23 @@ class OracleIndex:
         self._keep = [l2, bwt, sa]
         lib().cso_index_wrap(C.byref(self.idx), int(primary), l2.ctypes.data, bwt.ctypes.data, bwt.size, sa.ctypes.data, sa.size, sa_intv)
         return self
+
+    @classmethod
+    def build(cls, fwd_nt4, threads=8):
+        """index of a forward-strand genome (codes 0..3) by the oracle's naive suffix sort (cs_index_naive.c)"""
+        self = cls()
+        g = np.ascontiguousarray(fwd_nt4, dtype=np.uint8)
+        rc = lib().cso_index_build(g.ctypes.data, g.size, threads, C.byref(self.idx))
+        if rc:
+            raise RuntimeError("cso_index_build failed: %d" % rc)
+        return self
+
+    def arrays(self):
+        """(bwt words, sampled SA) as numpy copies"""
+        i = self.idx
+        bw = np.frombuffer((C.c_char * (int(i.bwt_size) * 4)).from_address(i.bwt), dtype="<u4").copy()
+        sa = np.frombuffer((C.c_char * (int(i.n_sa) * 8)).from_address(i.sa), dtype="<u8").copy()
+        return bw, sa
 
     def close(self):
         lib().cso_index_free(C.byref(self.idx))

@@ -12,6 +12,8 @@ What is produced (all data, no reference source text):
   g1/<reads>.<params>.npz            per-read sorted mem lists + SAL seeds + reference counters (ref_harness.cpp)
   g1/prims.npz                       known-answer vectors for bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_sa
   MANIFEST.json                      md5 of every file + the harness stderr summary per run
+  c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
+                                     md5 digests of its complete output (`make_golden.py config1` regenerates only this)
 """
 import gzip, hashlib, json, os, random, subprocess, sys
 import numpy as np
@@ -132,9 +134,48 @@ PARAM_SETS = {
 }
 
 
+def make_config1():
+    """BASELINE.json configs[0] (E. coli-size genome, 100 k x 100 bp reads): counters and output digests of the REAL reference.
+    Only a small JSON is committed; genome and reads are regenerated from tests/_data.config1_dataset() wherever needed."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _data
+    ref, reads, shuf = _data.config1_dataset()
+    out = {"recipe": "tests/_data.config1_dataset()", "genome_md5": hashlib.md5(ref.encode()).hexdigest(), "sets": {}}
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "ref.fa")
+        with open(fa, "w") as f:
+            f.write(">synthK12\n")
+            for i in range(0, len(ref), 70):
+                f.write(ref[i:i + 70] + "\n")
+        r = run([os.path.join(REFBIN, "bwaidx"), "-p", os.path.join(td, "ref"), fa])
+        if r.returncode:
+            sys.exit(r.stderr)
+        out["index_md5"] = {ext: md5(os.path.join(td, "ref." + ext)) for ext in ("bwt", "sa", "pac", "ann", "amb")}
+        for name, rd in (("sorted", reads), ("shuffled", shuf)):
+            txt = os.path.join(td, name + ".txt")
+            open(txt, "w").write("\n".join(rd) + "\n")
+            tmp = os.path.join(td, name + ".bin")
+            r = run([os.path.join(REFBIN, "ref_dump"), os.path.join(td, "ref"), txt, tmp])
+            if r.returncode:
+                sys.exit(r.stderr)
+            g = parse_gold(tmp)
+            c = [int(x) for x in g["counters"]]
+            assert c[7] == 0, "reference paths A and B disagree"
+            out["sets"][name] = {"reads_md5": md5(txt), "n_reads": c[0], "n_mems": c[1], "n_seeds": c[2], "bwt_queries": c[3], "bwt_calls": c[4],
+                                 "sal_queries": c[5], "sal_calls": c[6],
+                                 "digest": _data.digest_result(g["mem_off"], g["mems"], g["seed_off"], g["seed_rbeg"], g["seed_qbeg"], g["seed_len"]),
+                                 "harness": r.stderr.strip().splitlines()[-1]}
+    os.makedirs(os.path.join(HERE, "c1"), exist_ok=True)
+    json.dump(out, open(os.path.join(HERE, "c1", "config1.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "digest"} for k, v in out["sets"].items()}, indent=1))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":
+        return make_config1()
     rng = random.Random(20261003)
     d = os.path.join(HERE, "g1")
     os.makedirs(d, exist_ok=True)
@@ -195,6 +236,7 @@ def main():
         manifest["md5"]["g1/" + fn] = md5(os.path.join(d, fn))
     json.dump(manifest, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(manifest["runs"], indent=1))
+    make_config1()
 
 
 if __name__ == "__main__":

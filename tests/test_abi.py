@@ -88,7 +88,7 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
     import subprocess
     import compseed_amd.binding as b
     structs = {"cs_index_view_t": b.IndexView, "cs_params_t": b.Params, "cs_result_t": b.CResult, "cs_stats_t": b.Stats,
-               "cs_engine_options_t": b.EngineOptions}
+               "cs_engine_options_t": b.EngineOptions, "cs_traffic_t": b.Traffic, "cs_digest_t": b.Digest}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {']
     for cname, st in structs.items():
         src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -352,3 +352,55 @@ def test_device_sst_is_transparent(eng):
         assert stats[1]["bwt_calls"] < stats[0]["bwt_calls"]
         assert stats[0]["bwt_calls"] == stats[0]["bwt_queries"]
         assert stats[1]["bwt_calls"] < stats[1]["bwt_queries"]
+
+
+def test_result_digest_and_gather_reads(eng):
+    """cs_engine_result_digest == the host restatement over the downloaded arrays; cs_engine_gather_reads == slices of the full result"""
+    import compseed_amd as ca
+    bases, off = _data.load_reads("main100")
+    full = eng.seed_batch(bases, off)
+    want = tuple(ca.binding.digest_words(a) for a in (full.mem_off, full.mems, full.seed_off, full.seeds))
+    assert eng.result_digest() == want
+    ids = np.array([2999, 0, 7, 7, 1500, 2998, 1], dtype=np.uint64)
+    g = eng.gather_reads(ids)
+    assert g.n_reads == ids.size
+    for j, r in enumerate(ids.astype(int)):
+        assert np.array_equal(g.mems[int(g.mem_off[j]):int(g.mem_off[j + 1])], full.mems[int(full.mem_off[r]):int(full.mem_off[r + 1])])
+        assert np.array_equal(g.seeds[int(g.seed_off[j]):int(g.seed_off[j + 1])], full.seeds[int(full.seed_off[r]):int(full.seed_off[r + 1])])
+    nos = eng.seed_batch(bases, off, ca.Params(want_sal=0))
+    d = eng.result_digest()
+    assert d[0] == want[0] and d[1] == want[1] and d[2] == 0 and d[3] == 0
+    assert eng.gather_reads(ids).seeds is None and np.array_equal(eng.gather_reads(ids).mems, g.mems) and nos.n_seeds == 0
+    with pytest.raises(ca.CSError):
+        eng.gather_reads(np.array([3000], dtype=np.uint64))
+
+
+def test_config1_ecoli_size_set_on_the_gpu():
+    """BASELINE.json configs[0] on the device: index built on the GPU == bwaidx's (by md5), seeds == the reference's (by digest),
+    and with every shortcut off the device evaluates exactly the reference's 38,109,585 bwt_extend queries"""
+    import hashlib
+    import json
+    import compseed_amd as ca
+    want = json.load(open(os.path.join(_data.HERE, "golden", "c1", "config1.json")))
+    ref, reads, shuf = _data.config1_dataset()
+    ix = ca.Index.build(_data.codes_of(ref), 0)
+    bw, sa = ix.arrays()
+    v = ix.view
+    hdr = np.array([v.primary] + [v.L2[i] for i in range(1, 5)], dtype="<u8").tobytes()
+    assert hashlib.md5(hdr + bw.tobytes()).hexdigest() == want["index_md5"]["bwt"]
+    e = ca.Engine(ix, 0, count_sal_merged=1)
+    for order, rd in (("sorted", reads), ("shuffled", shuf)):
+        w = want["sets"][order]
+        bases, off = _data.pack_reads([r.encode() for r in rd])
+        for sst in (1, 0):
+            e.reset_stats()
+            got = e.seed_batch(bases, off, ca.Params(sst_mode=sst))
+            m = got.mems
+            d = _data.digest_result(got.mem_off, np.stack([m["x0"], m["x1"], m["x2"], m["info"]], axis=1), got.seed_off,
+                                    got.seeds["rbeg"], got.seeds["qbeg"], got.seeds["len"])
+            assert d == w["digest"], (order, sst)
+            st = e.stats()
+            assert st["sal_queries"] == w["sal_queries"] and st["sal_calls"] == w["sal_calls"]
+            if sst == 0:
+                assert st["bwt_queries"] == w["bwt_queries"] == 38109585
+    e.close(); ix.close()

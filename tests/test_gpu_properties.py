@@ -130,7 +130,8 @@ def test_sample_is_bit_exact_vs_oracle(world):
 
 
 @pytest.mark.parametrize("kw", [dict(k=15), dict(k=16, y=100), dict(k=17, r=1.0), dict(k=18, s=1), dict(k=19, c=50), dict(k=19, y=0),
-                                dict(k=19, y=5, r=1.2), dict(k=20), dict(k=25, r=1.1), dict(k=12, y=8)])
+                                dict(k=19, y=5, r=1.2), dict(k=20), dict(k=25, r=1.1), dict(k=12, y=8), dict(k=19, y=1), dict(k=19, y=2),
+                                dict(k=17, r=1.0, y=20), dict(k=19, r=1.0, y=20)])
 def test_parameter_sweep_shortcuts_on_off_and_oracle(world, kw):
     """every -k/-r/-y/-c/-s combination goes three ways: all shortcuts on (window scheme for 15 <= k <= 19, text arrays),
     everything off (`sst_mode=0`: the literal sweep), and the CPU oracle; reads include Ns and 1 % substitutions"""
@@ -150,59 +151,118 @@ def test_parameter_sweep_shortcuts_on_off_and_oracle(world, kw):
     assert np.array_equal(on.seeds[: int(on.seed_off[m])], want["seeds"])
 
 
-def test_long_reads_vs_oracle(world):
-    """40 reads of 5-30 kbp (1 % substitutions, a few Ns), far beyond the lengths the packed fields of the shortcuts were
-    sized on: every path has to fall back cleanly where a field would overflow; result identical to the oracle"""
-    ca, eng, g = world["ca"], world["eng"], world["g"]
-    rng = np.random.default_rng(99)
+def _long_reads(g, n, lo, hi, p_sub, p_n, seed):
+    rng = np.random.default_rng(seed)
     reads = []
-    for j in range(40):
-        ln = int(rng.integers(5000, 30000)); st = int(rng.integers(0, g.size - ln))
+    for j in range(n):
+        ln = int(rng.integers(lo, hi + 1)); st = int(rng.integers(0, g.size - ln))
         q = g[st: st + ln].copy()
         if j & 1:
             q = (3 - q[::-1]).astype(np.uint8)
-        mut = rng.random(ln) < 0.01
-        q[mut] = (q[mut] + rng.integers(1, 4, int(mut.sum()))).astype(np.uint8) % 4
-        q[rng.random(ln) < 0.0005] = 4
+        if p_sub > 0:
+            mut = rng.random(ln) < p_sub
+            q[mut] = (q[mut] + rng.integers(1, 4, int(mut.sum()))).astype(np.uint8) % 4
+        if p_n > 0:
+            q[rng.random(ln) < p_n] = 4
         reads.append(q)
     bases = np.frombuffer(b"ACGTN", np.uint8)[np.concatenate(reads)]
     off = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.uint64)
-    got = eng.seed_batch(bases, off)
+    return bases, off
+
+
+def _oracle_of(world):
     bw, sa = world["ix"].arrays()
     v = world["ix"].view
-    o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
-    want = o.seed_batch(bases, off, mode=1, threads=8)
+    return _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(k=255), dict(k=300, y=5), dict(k=254, r=1.0)])
+def test_long_reads_vs_oracle(world, kw):
+    """40 reads of 5-30 kbp (1 % substitutions, a few Ns), far beyond the lengths the packed fields of the shortcuts were
+    sized on: every path has to fall back cleanly where a field would overflow; result identical to the oracle.
+    -k 254 / 255 / 300: min_seed_len + 1 meets the 255 cap of the rep[] / lcp[] bytes (round 3 must then stay on the index)"""
+    ca, eng, g = world["ca"], world["eng"], world["g"]
+    bases, off = _long_reads(g, 40, 5000, 30000, 0.003 if kw else 0.01, 0.0005, 99)
+    got = eng.seed_batch(bases, off, ca.Params(**kw))
+    o = _oracle_of(world)
+    want = o.seed_batch(bases, off, _oracle.make_params(**kw), mode=1, threads=8)
+    assert want["stats"]["n_mems"] > 0
     assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"])
     assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
 
 
+@pytest.mark.parametrize("sst", [1, 0])
+def test_many_exact_long_reads_overflow_records(world, sst):
+    """300 error-free reads of 10 kbp: ~500 round-3 seeds per read against 64 slots, so round 3 fills the overflow records
+    (nb * 4 + 65536) on its side stream after the task loop has ended; the engine must notice, redo the batch with the
+    fused kernel and still return the oracle's result (the flag used to be read only inside the loop)"""
+    ca, eng, g = world["ca"], world["eng"], world["g"]
+    bases, off = _long_reads(g, 300, 10000, 10000, 0.0, 0.0, 7)
+    eng.reset_stats()
+    got = eng.seed_batch(bases, off, ca.Params(sst_mode=sst))
+    st = eng.stats()
+    assert st["overflow_kernel_launches"] > 0 or st["overflow_mems"] > 0
+    o = _oracle_of(world)
+    want = o.seed_batch(bases, off, mode=1, threads=8)
+    assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"])
+    assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
+    assert int(np.diff(want["mem_off"].astype(np.int64)).max()) > 64
+
+
 def test_full_baseline_size_properties():
-    """BASELINE configs[1] shape: hg19-size index, 10 M x 150 bp reads, defaults; cheap size-independent checks on device
-    results without copying 5 GB back: counts, sortedness, filters, and a checksum that must not change between two runs."""
+    """BASELINE configs[1] shape: hg19-size index (rows > 2^32: the 64-bit suffix-array / inverse-SA instantiation), 10 M x 150 bp
+    reads.  For the default parameters and for configs[4]'s aggressive re-seeding (-r 1.0 -y 20):
+      * every shortcut on vs `sst_mode = 0` (the literal algorithm on the FM index): device-side digests of all four result
+        arrays over all 10 M reads must be equal -- no 6 GB download;
+      * a strided sample of 20,000 reads (every 500th, so the whole genome incl. its repeats is covered) bit-exact vs the oracle;
+      * cheap size-independent checks streamed through the host: counts, sortedness, filters; two runs give the same digest."""
     import torch
     import compseed_amd as ca
     import synth
+    n = 10_000_000
     G = synth.make_genome(3_100_000_000, seed=20261003, device="cuda")
     ix = ca.Index.build(G.cpu().numpy(), 0)
-    bases, off = synth.make_reads(G, 10_000_000, 150, seed=777, p_sub=0.005, sort=True)
+    bases, off = synth.make_reads(G, n, 150, seed=777, p_sub=0.005, sort=True)
     del G
     torch.cuda.empty_cache()
+    assert ix.view.seq_len + 1 > 2**32
     eng = ca.Engine(ix, 0)
-    sums = []
-    for _ in range(2):
-        torch.cuda.synchronize()
-        r = eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), 10_000_000, bases.numel())
-        mo = eng.download(r.ptr["mem_off"], np.uint64, 10_000_001)
-        assert int(mo[-1]) == r.n_mems and (np.diff(mo.astype(np.int64)) >= 0).all()
-        chk = 0
-        step = 4_000_000
-        for s in range(0, r.n_mems, step):                                   # stream the mems through the host in pieces
-            k = min(step, r.n_mems - s)
-            m = eng.download(r.ptr["mems"] + s * 32, ca.INTV_DT, k)
-            beg = (m["info"] >> np.uint64(32)).astype(np.int64); end = (m["info"] & np.uint64(0xffffffff)).astype(np.int64)
-            assert (end - beg >= 19).all() and (end <= 150).all() and (m["x2"] >= 1).all()
-            chk ^= int(np.bitwise_xor.reduce(m["x0"] * np.uint64(0x9E3779B97F4A7C15) + m["x1"] + (m["info"] << np.uint64(1)) + m["x2"]))
-        rd_first = mo[:-1][np.diff(mo.astype(np.int64)) > 0]
-        sums.append((r.n_mems, r.n_seeds, chk, int(rd_first.size)))
-    assert sums[0] == sums[1] and sums[0][0] > 50_000_000
-    eng.close(); ix.close()
+    bw, sa = ix.arrays()
+    v = ix.view
+    o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
+    ids = np.arange(0, n, n // 20000, dtype=np.uint64)[:20000]
+    sel = (ids[:, None].astype(np.int64) * 150 + np.arange(150)[None, :]).reshape(-1)
+    hb = bases[torch.from_numpy(sel).to(bases.device)].cpu().numpy()
+    ho = (np.arange(ids.size + 1, dtype=np.uint64) * np.uint64(150))
+    torch.cuda.synchronize()
+    for kw in (dict(), dict(r=1.0, y=20)):
+        r = eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
+        d_on = eng.result_digest()
+        st = eng.stats()
+        assert st["reseed_text_calls"] > 0 and st["r3_text_seeds"] > 0 and st["sweep_text_calls"] > 0      # the shortcuts did run
+        got = eng.gather_reads(ids)
+        want = o.seed_batch(hb, ho, _oracle.make_params(**kw), mode=1, threads=16)
+        assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"]), kw
+        assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"]), kw
+        if not kw:  # stream the mems through the host in pieces: filters and sortedness over all 10 M reads
+            mo = eng.download(r.ptr["mem_off"], np.uint64, n + 1)
+            assert int(mo[-1]) == r.n_mems and (np.diff(mo.astype(np.int64)) >= 0).all() and r.n_mems > 50_000_000
+            first = np.zeros(r.n_mems + 1, dtype=bool); first[mo.astype(np.int64)] = True
+            step = 4_000_000
+            for s0 in range(0, r.n_mems, step):
+                k = min(step, r.n_mems - s0)
+                m = eng.download(r.ptr["mems"] + s0 * 32, ca.INTV_DT, k)
+                beg = (m["info"] >> np.uint64(32)).astype(np.int64); end = (m["info"] & np.uint64(0xffffffff)).astype(np.int64)
+                assert (end - beg >= 19).all() and (end <= 150).all() and (m["x2"] >= 1).all()
+                inside = ~first[s0 + 1: s0 + k]                                   # consecutive mems of the same read
+                assert (m["info"][1:][inside] >= m["info"][:-1][inside]).all()    # sorted by info (comp_seed.cpp:2301)
+            del first
+        eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
+        assert eng.result_digest() == d_on                                         # deterministic despite atomics / task order
+        eng.reset_stats()
+        eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(sst_mode=0, **kw))
+        st0 = eng.stats()
+        assert st0["reseed_text_calls"] == 0 and st0["r3_text_seeds"] == 0 and st0["bwt_calls"] == st0["bwt_queries"]
+        assert eng.result_digest() == d_on, kw                                     # all 10 M reads, all four arrays
+        eng.reset_stats()
+    o.close(); eng.close(); ix.close()

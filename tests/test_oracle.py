@@ -98,3 +98,58 @@ def test_nt4_input_equals_ascii(oidx):
     b = oidx.seed_batch(tbl[bases], off)
     for k in ("mem_off", "mems", "seed_off", "seeds"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_naive_index_builder_reproduces_the_bwaidx_fixture():
+    """oracle/cs_index_naive.c (comparison sort of all suffixes) == the .bwt/.sa the reference's bwaidx wrote for the fixture"""
+    f = _data.load_bwt_files()
+    o = _oracle.OracleIndex.build(_data.load_pac_forward(), threads=4)
+    bw, sa = o.arrays()
+    assert o.idx.primary == f["primary"] and list(o.idx.L2)[1:] == [int(x) for x in f["L2"]]
+    assert np.array_equal(bw, f["bwt"]) and np.array_equal(sa, f["sa"])
+    o.close()
+
+
+@pytest.fixture(scope="module")
+def config1():
+    """BASELINE.json configs[0]: E. coli K-12-size genome, 100 k x 100 bp reads (CPU plumbing + bit-exact seed diff)"""
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(_data.HERE, "golden", "c1", "config1.json")))
+    ref, reads, shuf = _data.config1_dataset()
+    assert hashlib.md5(ref.encode()).hexdigest() == want["genome_md5"], "the generator no longer reproduces the pinned genome"
+    o = _oracle.OracleIndex.build(_data.codes_of(ref), threads=8)
+    yield dict(want=want, o=o, sets={"sorted": reads, "shuffled": shuf})
+    o.close()
+
+
+def test_config1_index_is_bwaidx_identical(config1):
+    import hashlib
+    o, want = config1["o"], config1["want"]
+    bw, sa = o.arrays()
+    i = o.idx
+    hdr = np.array([i.primary] + list(i.L2)[1:], dtype="<u8").tobytes()
+    assert hashlib.md5(hdr + bw.tobytes()).hexdigest() == want["index_md5"]["bwt"]                       # bwt_dump_bwt, bwt.c:385-394
+    sa_hdr = np.array([i.primary] + list(i.L2)[1:] + [i.sa_intv, i.seq_len], dtype="<u8").tobytes()
+    assert hashlib.md5(sa_hdr + sa[1:].tobytes()).hexdigest() == want["index_md5"]["sa"]                  # bwt_dump_sa, bwt.c:396-407
+
+
+@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+def test_config1_counters_and_output_are_the_references(config1, order):
+    """the reference's own run of this set: 38,109,585 bwt_extend queries, 28,527,263 (sorted) /
+    29,553,396 (shuffled) real calls under the 512-read SST policy, 569,493 SAL queries -- and the complete output, by digest"""
+    import hashlib
+    w = config1["want"]["sets"][order]
+    reads = config1["sets"][order]
+    txt = ("\n".join(reads) + "\n").encode()
+    assert hashlib.md5(txt).hexdigest() == w["reads_md5"]
+    bases, off = _data.pack_reads([r.encode() for r in reads])
+    got = config1["o"].seed_batch(bases, off, mode=1, sst_batch=512, want_sal=True, threads=1)  # one thread: SST batches as `CompSeed -t 1`
+    st = got["stats"]
+    assert (st["bwt_queries"], st["bwt_calls"], st["sal_queries"], st["sal_calls"]) == (w["bwt_queries"], w["bwt_calls"], w["sal_queries"], w["sal_calls"])
+    assert w["bwt_queries"] == 38109585 and w["sal_queries"] == 569493
+    assert (st["n_mems"], st["n_seeds"]) == (w["n_mems"], w["n_seeds"])
+    m = got["mems"]
+    d = _data.digest_result(got["mem_off"], np.stack([m["x0"], m["x1"], m["x2"], m["info"]], axis=1), got["seed_off"],
+                            got["seeds"]["rbeg"], got["seeds"]["qbeg"], got["seeds"]["len"])
+    assert d == w["digest"]
