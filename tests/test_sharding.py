@@ -34,6 +34,40 @@ d.close()
 '''
 
 
+WORKER2 = r'''
+import os, sys, pickle
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import numpy as np, torch
+import _data, _oracle
+from compseed_amd.sharding import Dist, Collectives
+d = Dist("gloo")
+co = Collectives(d, "cpu")
+# the index travels from rank 0 (which "loaded" it) to the others; reads are ingested by rank 0 only
+arr = None
+if d.rank == 0:
+    f = _data.load_bwt_files()
+    arr = dict(primary=f["primary"], L2=[int(x) for x in f["L2"]], bwt=f["bwt"], sa=f["sa"], sa_intv=f["sa_intv"])
+arr = co.broadcast_index(arr)
+o = _oracle.OracleIndex.from_arrays(arr["primary"], arr["L2"], arr["bwt"], arr["sa"], arr["sa_intv"])
+bases = off = None
+if d.rank == 0:
+    b, f = _data.load_reads(sys.argv[2])
+    bases, off = torch.from_numpy(b), torch.from_numpy(f.astype(np.int64))
+mb, mo = co.scatter_reads(bases, off)
+res = o.seed_batch(mb.numpy(), mo.numpy().astype(np.uint64), mode=1, threads=1)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).view(np.int64).copy())
+g = co.gather_results(t(res["mem_off"]), t(res["mems"]), t(res["seed_off"]), t(res["seeds"]))
+if d.rank == 0:
+    out = dict(mem_off=g["mem_off"].numpy().astype(np.uint64), mems=g["mems"].numpy().view(_oracle.INTV_DT),
+               seed_off=g["seed_off"].numpy().astype(np.uint64), seeds=g["seeds"].numpy().view(_oracle.SEED_DT),
+               world=d.world, mine=int(mo.numel() - 1))
+    pickle.dump(out, open(sys.argv[1], "wb"))
+else:
+    assert g is None
+d.close()
+'''
+
+
 def test_shard_bounds_cover_and_balance():
     from compseed_amd.sharding import shard_bounds
     for n in (0, 1, 7, 512, 10_000_001):
@@ -63,5 +97,38 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     for k in ("mem_off", "mems", "seed_off", "seeds"):
         assert np.array_equal(got[k], want[k]), k
     z, _ = _data.load_golden("sorted150", "default")
+    assert np.array_equal(got["mem_off"], z["mem_off"]) and np.array_equal(got["seeds"]["rbeg"], z["seed_rbeg"])
+    o.close()
+
+
+def _run_workers(tmp_path, body, args, port, nproc=2):
+    script = tmp_path / "worker.py"
+    script.write_text(body % dict(root=ROOT, here=HERE))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+import pytest
+
+
+@pytest.mark.parametrize("name,nproc", [("sorted150", 2), ("ragged", 3)])
+def test_index_broadcast_scatter_gather_over_gloo(tmp_path, name, nproc):
+    """the north_star's data movement with world_size > 1: rank 0 owns index and chunk; broadcast_index, two-phase scatter_reads,
+    per-rank seeding, two-phase gather_results; the gathered CSR equals the single-process result and the reference golden
+    (`ragged` has empty reads, so some ranks send zero-length payloads)"""
+    import pickle
+    import _oracle
+    out = tmp_path / "gathered.pkl"
+    _run_workers(tmp_path, WORKER2, [out, name], 29551 + nproc, nproc)
+    got = pickle.load(open(out, "rb"))
+    bases, off = _data.load_reads(name)
+    o = _oracle.OracleIndex(_data.PREFIX)
+    want = o.seed_batch(bases, off, mode=1, threads=1)
+    assert got["world"] == nproc and got["mine"] == (off.size - 1) // nproc
+    for k in ("mem_off", "mems", "seed_off", "seeds"):
+        assert np.array_equal(got[k], want[k]), k
+    z, _ = _data.load_golden(name, "default")
     assert np.array_equal(got["mem_off"], z["mem_off"]) and np.array_equal(got["seeds"]["rbeg"], z["seed_rbeg"])
     o.close()
