@@ -13,7 +13,8 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
            "cs_index_build_flags", "cs_index_save",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
-           "cs_engine_seed_batch_device", "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
+           "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free",
+           "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync"]
 
@@ -55,7 +56,8 @@ class EngineOptions(C.Structure):
     _fields_ = [("full_sa", C.c_int32), ("sa64", C.c_int32), ("text_mode", C.c_int32), ("text_arrays", C.c_int32),
                 ("jump_k", C.c_int32), ("kmer_filter", C.c_int32), ("fused", C.c_int32), ("mem_cap", C.c_int32),
                 ("lep_arena_mb", C.c_int64), ("max_raw_mb", C.c_int64), ("r3_text_iter", C.c_int32),
-                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("pipeline_reads", C.c_int32), ("expand_threads", C.c_int32),
+                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 5)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -69,6 +71,25 @@ class EngineOptions(C.Structure):
 class CResult(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_mems", C.c_uint64), ("n_seeds", C.c_uint64), ("mem_off", C.c_void_p),
                 ("mems", C.c_void_p), ("seed_off", C.c_void_p), ("seeds", C.c_void_p)]
+
+
+class CPacked(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_mems", C.c_uint64), ("n_seeds", C.c_uint64), ("mem_format", C.c_int32), ("max_occ", C.c_int32),
+                ("mem_off", C.c_void_p), ("mems", C.c_void_p), ("seed_off", C.c_void_p), ("seed_rbeg", C.c_void_p)]
+
+
+MEM16_DT = np.dtype([("w0", "<u8"), ("w1", "<u8")])   # cs_mem16_t
+
+
+def unpack_mems16(p):
+    """numpy restatement of cs_unpack_mem for CS_MEM_PACKED16 records -> INTV_DT array"""
+    out = np.zeros(p.size, dtype=INTV_DT)
+    m33 = np.uint64((1 << 33) - 1)
+    out["x0"] = p["w0"] & m33
+    out["x1"] = p["w1"] & m33
+    out["x2"] = (p["w0"] >> np.uint64(33)) | ((p["w1"] >> np.uint64(63)) << np.uint64(31))
+    out["info"] = (((p["w1"] >> np.uint64(33)) & np.uint64(0x7fff)) << np.uint64(32)) | ((p["w1"] >> np.uint64(48)) & np.uint64(0x7fff))
+    return out
 
 
 class Stats(C.Structure):
@@ -162,6 +183,11 @@ def load_library():
     L.cs_engine_result_digest.argtypes = [vp, C.POINTER(Digest)]
     L.cs_engine_gather_reads.argtypes = [vp, i64, vp, C.POINTER(CResult)]
     L.cs_engine_traffic_model.argtypes = [vp, C.POINTER(Traffic)]
+    L.cs_engine_seed_batch_packed.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.POINTER(CPacked)]
+    L.cs_engine_submit.argtypes = [vp, C.POINTER(Params), i64, vp, u64p]
+    L.cs_engine_collect_packed.argtypes = [vp, C.POINTER(CPacked)]
+    L.cs_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.cs_host_free.argtypes = [vp]
     L.cs_engine_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cs_engine_reset_stats.argtypes = [vp]
     L.cs_engine_reset_stats.restype = None
@@ -278,6 +304,29 @@ def _view(ptr, dt, n, copy=True):
     return a.copy() if copy else a  # copy=False: a view of the engine's pinned buffer, valid until the next call
 
 
+class PinnedArray(np.ndarray):
+    """uint8 numpy array over pinned host memory from cs_host_alloc (freed with the array)"""
+    _ptr = None
+
+    def __del__(self):
+        if self._ptr:
+            try:
+                load_library().cs_host_free(C.c_void_p(self._ptr))
+            except Exception:
+                pass
+            self._ptr = None
+
+
+def pinned_array(nbytes):
+    """uint8 array of `nbytes` in pinned host memory (cs_host_alloc): what an integration would read its chunk of reads into"""
+    p = C.c_void_p()
+    _check(load_library().cs_host_alloc(int(nbytes), C.byref(p)))
+    buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=np.uint8).view(PinnedArray)
+    a._ptr = p.value
+    return a
+
+
 class Engine:
     """One GPU, one resident index (cs_engine_t)."""
 
@@ -307,11 +356,47 @@ class Engine:
         """Host buffers in, numpy CSR out (cs_engine_seed_batch).  copy=False returns views of the engine's pinned
         result buffers (valid until the next call on this engine) instead of copies."""
         params = params or Params()
-        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        if not isinstance(bases, PinnedArray):
+            bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         res = CResult()
         _check(self._L.cs_engine_seed_batch(self._h, C.byref(params), offsets.size - 1, bases.ctypes.data, offsets.ctypes.data, C.byref(res)))
         return Result(res, False, bool(params.want_sal), copy)
+
+    def seed_batch_packed(self, bases, offsets, params=None):
+        """Host buffers in, the PACKED CSR (what crosses PCIe) out as views of the engine's pinned buffers: dict(mem_format, mem_off,
+        mems (MEM16_DT or INTV_DT), seed_off, seed_rbeg, max_occ); valid until the next call (cs_engine_seed_batch_packed)"""
+        params = params or Params()
+        if not isinstance(bases, PinnedArray):
+            bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        res = CPacked()
+        _check(self._L.cs_engine_seed_batch_packed(self._h, C.byref(params), offsets.size - 1, bases.ctypes.data, offsets.ctypes.data, C.byref(res)))
+        return self._packed(res)
+
+    def submit(self, bases, offsets, params=None):
+        """queue a batch (cs_engine_submit); bases / offsets must be contiguous uint8 / uint64 arrays that stay alive and unchanged until collected"""
+        params = params or Params()
+        assert bases.dtype == np.uint8 and offsets.dtype == np.uint64 and bases.flags.c_contiguous and offsets.flags.c_contiguous
+        self._inflight = getattr(self, "_inflight", []) + [(bases, offsets, params)]
+        _check(self._L.cs_engine_submit(self._h, C.byref(params), offsets.size - 1, bases.ctypes.data, offsets.ctypes.data))
+
+    def collect_packed(self):
+        """block until the oldest submitted batch is complete (cs_engine_collect_packed); same dict as seed_batch_packed"""
+        res = CPacked()
+        _check(self._L.cs_engine_collect_packed(self._h, C.byref(res)))
+        self._inflight = getattr(self, "_inflight", [])[1:]
+        return self._packed(res)
+
+    @staticmethod
+    def _packed(res):
+        n = int(res.n_reads)
+        sal = bool(res.seed_off)
+        return dict(n_reads=n, n_mems=int(res.n_mems), n_seeds=int(res.n_seeds), mem_format=int(res.mem_format), max_occ=int(res.max_occ),
+                    mem_off=_view(res.mem_off, "<u8", n + 1, False),
+                    mems=_view(res.mems, MEM16_DT if res.mem_format == 1 else INTV_DT, int(res.n_mems), False),
+                    seed_off=_view(res.seed_off, "<u8", n + 1, False) if sal else None,
+                    seed_rbeg=_view(res.seed_rbeg, "<i8", int(res.n_seeds), False) if sal else None)
 
     def seed_batch_device(self, d_bases, d_offsets, n_reads, n_bases, params=None):
         """Device pointers (ints) in, device pointers out (cs_engine_seed_batch_device): no PCIe traffic in the call."""

@@ -7,6 +7,11 @@
 #include "smem_split.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,6 +56,7 @@ extern "C" void cs_engine_options_default(cs_engine_options_t *o)
 	memset(o, 0, sizeof *o);
 	o->full_sa = 1; o->sa64 = 0; o->text_mode = 1; o->text_arrays = 1; o->jump_k = 15; o->kmer_filter = 1; o->fused = 0;
 	o->mem_cap = 64; o->lep_arena_mb = 32768; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
+	o->pipeline_reads = 5000000; o->expand_threads = 16;
 }
 
 // ------------------------------------------------------------------------------------------------ grow-only buffers
@@ -73,27 +79,46 @@ template <typename T> struct DevBuf {
 	}
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-template <typename T> struct PinBuf {
+// grow-only plain host memory (the expanded results of cs_engine_seed_batch; `keep_n` elements survive a reallocation)
+template <typename T> struct HostBuf {
 	T *p = nullptr; size_t cap = 0;
-	int reserve(size_t n)
+	int reserve(size_t n, size_t keep_n = 0)
+	{
+		if (n <= cap) return 0;
+		size_t want = std::max(n, cap + cap / 4);
+		T *q = (T *)malloc(want * sizeof(T));
+		if (!q) return 1;
+		if (p && keep_n) memcpy(q, p, keep_n * sizeof(T));
+		free(p);
+		p = q; cap = want;
+		return 0;
+	}
+	void release() { free(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+	T *p = nullptr, *dp = nullptr; size_t cap = 0; // dp: the same memory as the device addresses it (kernels may store into it)
+	int reserve(size_t n, bool keep = false, size_t keep_n = 0)
 	{
 		if (n <= cap) return CS_OK;
 		size_t want = std::max(n, cap + cap / 2);
+		T *q = nullptr;
+		HIP_TRY(hipHostMalloc((void **)&q, want * sizeof(T), hipHostMallocDefault));
+		if (keep && p && keep_n) memcpy(q, p, keep_n * sizeof(T));
 		if (p) (void)hipHostFree(p);
-		p = nullptr; cap = 0;
-		HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
-		cap = want;
+		p = q; cap = want; dp = nullptr;
+		void *d = nullptr;
+		if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) dp = (T *)d; else (void)hipGetLastError();
 		return CS_OK;
 	}
-	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
 };
 
 struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
 	cs_engine_options_t opt{};
-	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; // stream2: the independent round-3 chains; stream3: wide sweeps
-	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr, ev_wc = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; // stream2: round 3 (low priority); stream3: wide sweeps + calls without LEPs
+	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
@@ -119,6 +144,12 @@ struct cs_engine {
 	int occ_win = 5; // ... of bwd_win_kernel
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
 	size_t lep_arena_bytes = (size_t)32 << 30;
+	// host variants (seed_host_pipelined): copy streams, two input slots, two pack slots, pinned packed results, expanded results
+	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[2] = {nullptr, nullptr};
+	DevBuf<uint8_t> hp_in[2], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[2], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<int64_t> hp_pk_rbeg[2];
+	PinBuf<uint64_t> hp_moff[2], hp_soff[2]; PinBuf<uint8_t> hp_mems[2]; PinBuf<int64_t> hp_rbeg[2]; // two pinned result slots
+	struct HostPipe *hp = nullptr;
+	HostBuf<cs_intv_t> x_mems; HostBuf<cs_seed_t> x_seeds;
 	cs_stats_t st{};
 	DevBuf<unsigned long long> d_evc; uint64_t stream_bytes = 0; // byte model: event counters [N_KID][N_EV] on the device, stream part on the host
 	struct { bool valid = false; int64_t n_reads = 0; uint64_t n_mems = 0, n_seeds = 0; int want_sal = 0; } last; // the result held in d_mems / d_seeds
@@ -223,8 +254,15 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		HIP_TRY(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_wa, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_wb, hipEventDisableTiming));
-		HIP_TRY(hipStreamCreateWithFlags(&e->stream4, hipStreamNonBlocking));
-		HIP_TRY(hipEventCreateWithFlags(&e->ev_wc, hipEventDisableTiming));
+		// The runtime multiplexes the normal-priority streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+		// default), and a stream that shares its queue with a 30-ms download stands still for 30 ms -- measured: the seeding kernels
+		// of a sub-batch took 65 instead of 45 ms beside the download of the previous one.  So the engine keeps to three normal
+		// streams (main, side, upload), round 3 runs at low and the downloads at high priority, which have queues of their own.
+		HIP_TRY(hipStreamCreateWithFlags(&e->s_up, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithPriority(&e->s_down, hipStreamNonBlocking, hi));
+		for (auto &ev : e->hp_ev_pk) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		for (auto &ev : e->hp_ev_dn) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		for (auto &ev : e->hp_ev_done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 	}
 
 	if (v->seq_len == 0 || v->seq_len != v->L2[4] || v->L2[0] != 0) return fail(CS_EINVAL, "index view: L2 / seq_len inconsistent");
@@ -393,10 +431,12 @@ extern "C" int cs_engine_create_opts(const cs_index_view_t *index, int device, c
 	return CS_OK;
 }
 
+static void pipe_stop(cs_engine *e);
 extern "C" void cs_engine_destroy(cs_engine_t *e)
 {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
+	pipe_stop(e);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
@@ -406,14 +446,20 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_evc.release(); e->d_sel.release(); e->d_sel_moff.release(); e->d_sel_soff.release(); e->d_sel_mems.release(); e->d_sel_seeds.release();
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
+	for (int k = 0; k < 2; ++k) { e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rbeg[k].release(); }
+	for (int k = 0; k < 2; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rbeg[k].release(); }
+	e->x_mems.release(); e->x_seeds.release();
+	for (auto &ev : e->hp_ev_done) if (ev) (void)hipEventDestroy(ev);
+	for (auto &ev : e->hp_ev_pk) if (ev) (void)hipEventDestroy(ev);
+	for (auto &ev : e->hp_ev_dn) if (ev) (void)hipEventDestroy(ev);
+	if (e->s_up) (void)hipStreamDestroy(e->s_up);
+	if (e->s_down) (void)hipStreamDestroy(e->s_down);
 	for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
 	if (e->ev_r3a) (void)hipEventDestroy(e->ev_r3a);
 	if (e->ev_r3b) (void)hipEventDestroy(e->ev_r3b);
 	if (e->ev_wa) (void)hipEventDestroy(e->ev_wa);
 	if (e->ev_wb) (void)hipEventDestroy(e->ev_wb);
 	if (e->stream3) (void)hipStreamDestroy(e->stream3);
-	if (e->ev_wc) (void)hipEventDestroy(e->ev_wc);
-	if (e->stream4) (void)hipStreamDestroy(e->stream4);
 	if (e->stream2) (void)hipStreamDestroy(e->stream2);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
@@ -528,6 +574,25 @@ __global__ void count_distinct_kernel(const uint64_t *keys, uint64_t n, unsigned
 	if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// A few counter words from the device to the host.  Not a hipMemcpyAsync: that would queue behind whatever large transfer the
+// copy engine is busy with (the results of the previous sub-batch on their way to the host, cs_engine_seed_batch), and the
+// SMEM stage reads its counters back ten times per pass.  A one-wave kernel stores the words straight into pinned host memory.
+__global__ void fetch_words_kernel(unsigned long long *dst_host, const unsigned long long *src, int n)
+{
+	if ((int)threadIdx.x < n) dst_host[threadIdx.x] = src[threadIdx.x];
+	__threadfence_system();
+}
+template <typename T>
+static int fetch_words(PinBuf<unsigned long long> &h, size_t at, const T *d_src, int n, hipStream_t s)
+{
+	static_assert(sizeof(T) == 8, "64-bit words");
+	if (h.dp && n <= 64) {
+		hipLaunchKernelGGL(fetch_words_kernel, dim3(1), dim3(64), 0, s, h.dp + at, (const unsigned long long *)d_src, n);
+		HIP_TRY(hipGetLastError());
+	} else HIP_TRY(hipMemcpyAsync(h.p + at, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+	return CS_OK;
+}
+
 static inline unsigned grid_for(int64_t n, int block) { return (unsigned)std::max<int64_t>(1, (n + block - 1) / block); }
 
 constexpr int SMEM_BLOCK = 256;
@@ -609,7 +674,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	const int rc = run_smem_split_body(e, par, d_off, nb, max_len, n_ovf_out);
 	if (rc != CS_OK) { // every early exit: kernels on the side streams may still be appending to buffers the next call reuses
 		const std::string keep = g_err;
-		(void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4);
+		(void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
 		(void)hipGetLastError();
 		g_err = keep;
 	}
@@ -727,18 +792,14 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				                              (const BTask *)e->d_bq.p, cn, C + 5);
 				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
 				                        (const BTask *)e->d_bq.p, cn, C + 5);
-				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
-				if (A.win) { // the calls without stored LEPs, beside the others on a stream of their own
-					HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
-					LAUNCH_CT(count, bwd_win0_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), e->stream4, A,
+				if (A.win) // the calls without stored LEPs, beside the others on the same side stream, behind the handful of wide sweeps
+					LAUNCH_CT(count, bwd_win0_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), e->stream3, A,
 					          (const BTask *)e->d_bq.p, cn);
-					HIP_TRY(hipEventRecord(e->ev_wc, e->stream4));
-				}
+				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
 				if (A.win) LAUNCH_CT(count, bwd_win_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 7) / 8)), s, A, (const BTask *)e->d_bq.p, cn, C + 2);
 				else LAUNCH_CT(count, bwd_all_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), s, A, (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // all must be done before the slots and the LEP arena are reused
-				if (A.win) HIP_TRY(hipStreamWaitEvent(s, e->ev_wc, 0));
 			}
 			c0 += cn;
 		}
@@ -750,7 +811,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 			HIP_TRY(hipGetLastError());
 		}
 		if (r3_text && !r3t_launched && iter + 1 >= r3t_iter) { CS_TRY(launch_r3text()); r3t_launched = true; }
-		HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		CS_TRY(fetch_words(e->h_sctr, 0, C, 32, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) return 1; // a queue or the overflow records ran full: the caller redoes the sub-batch with the fused kernel
 		// byte model, stream part: this iteration's queue words read (8 B), words pushed (8 B + 8 B side word), and per slot a
@@ -766,7 +827,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 	if (r3_async && !r3_launched) { CS_TRY(launch_r3()); r3_launched = true; }
 	if (r3_async || r3_text) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
 	HIP_TRY(hipEventRecord(e->ev[1], s));
-	HIP_TRY(hipMemcpyAsync(H, C, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	CS_TRY(fetch_words(e->h_sctr, 0, C, 32, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if (H[7]) return 1; // round 3 is joined only here: it may have run the overflow records full after the last check in the loop
 	CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
@@ -778,6 +839,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 }
 
 // ------------------------------------------------------------------------------------------------ the hot path
+static bool pipe_busy(const cs_engine *e);
 static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
                             uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out)
 {
@@ -795,7 +857,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	// read lengths: MAX_READ_LEN 65535 (comp_seed.h:39; the reference aborts at main.cpp:83-86)
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, 3 * sizeof(unsigned long long), s));
 	hipLaunchKernelGGL(max_len_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads, 256), (int64_t)e->n_cu * 8)), dim3(256), 0, s, d_off, n_reads, n_bases, e->d_ctr.p + 3, e->d_ctr.p + 4);
-	HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	CS_TRY(fetch_words(e->h_ctr, 0, e->d_ctr.p, 8, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if (e->h_ctr.p[4]) return fail(CS_EINVAL, "offsets must start at 0, be non-decreasing and end at n_bases");
 	uint32_t max_len = (uint32_t)e->h_ctr.p[3];
@@ -835,7 +897,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 					HIP_TRY(rocprim::radix_sort_pairs((void *)e->d_tmp2.p, tb, e->d_okey.p, e->d_okey2.p, e->d_oidx.p, e->d_oidx2.p, (size_t)n_ovf2, 0u, 32u, s));
 				}
 				CS_TRY(scan_counts(e, e->d_cnt.p, e->d_mem_off.p + b0, (size_t)nb, total_mems));
-				HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_mem_off.p + b0 + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+				CS_TRY(fetch_words(e->h_ctr, 0, e->d_mem_off.p + b0 + nb, 1, s));
 				HIP_TRY(hipStreamSynchronize(s));
 				uint64_t new_total = e->h_ctr.p[0];
 				CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
@@ -856,7 +918,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		CS_TRY(launch_smem(e, par, d_off + b0, nullptr, nb, e->d_out.p, e->d_cnt.p, cap, max_len));
 		HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, sizeof(unsigned long long), s));
 		hipLaunchKernelGGL(collect_overflow_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, e->d_cnt.p, nb, cap, 0u, e->d_ovf.p, e->d_ctr.p + 2);
-		HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		CS_TRY(fetch_words(e->h_ctr, 0, e->d_ctr.p, 8, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.seed_kernel_ms));
 		e->st.bwt_queries += e->h_ctr.p[1]; e->st.bwt_calls += e->h_ctr.p[1];
@@ -875,7 +937,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 				// reuse the overflow counter to see whether any task still does not fit
 				hipLaunchKernelGGL(collect_overflow_kernel, dim3(grid_for(n_ovf, 256)), dim3(256), 0, s, e->d_cnt2.p, n_ovf, cap2, 0u,
 				                   (uint32_t *)e->d_tmp2.p, e->d_ctr.p + 2);
-				HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+				CS_TRY(fetch_words(e->h_ctr, 0, e->d_ctr.p, 8, s));
 				HIP_TRY(hipStreamSynchronize(s));
 				CS_TRY(add_event_ms(e, e->ev[0], e->ev[1], &e->st.overflow_kernel_ms));
 				e->st.bwt_queries += e->h_ctr.p[1]; e->st.bwt_calls += e->h_ctr.p[1];
@@ -888,7 +950,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		}
 		// offsets of this sub-batch, continuing the running total
 		CS_TRY(scan_counts(e, e->d_cnt.p, e->d_mem_off.p + b0, (size_t)nb, total_mems));
-		HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_mem_off.p + b0 + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		CS_TRY(fetch_words(e->h_ctr, 0, e->d_mem_off.p + b0 + nb, 1, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		uint64_t new_total = e->h_ctr.p[0];
 		CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
@@ -921,7 +983,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 			CS_TRY(e->d_tmp2.reserve(tmp + 16));
 			HIP_TRY(rocprim::exclusive_scan((void *)e->d_tmp2.p, tmp, cnt64, som.p, (uint64_t)0, (size_t)total_mems + 1, rocprim::plus<uint64_t>(), s));
 		}
-		HIP_TRY(hipMemcpyAsync(e->h_ctr.p, som.p + total_mems, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		CS_TRY(fetch_words(e->h_ctr, 0, som.p + total_mems, 1, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		uint64_t total_seeds = e->h_ctr.p[0];
 		CS_TRY(e->d_seeds.reserve((size_t)total_seeds + 16));
@@ -943,7 +1005,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 			HIP_TRY(rocprim::radix_sort_keys((void *)e->d_tmp2.p, tb, kb, (size_t)total_seeds, 0u, bits, s));
 			HIP_TRY(hipMemsetAsync(e->d_ctr.p + 5, 0, sizeof(unsigned long long), s));
 			hipLaunchKernelGGL(count_distinct_kernel, dim3((unsigned)e->n_cu * 8), dim3(256), 0, s, (const uint64_t *)kb.current(), total_seeds, e->d_ctr.p + 5);
-			HIP_TRY(hipMemcpyAsync(e->h_ctr.p + 5, e->d_ctr.p + 5, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+			CS_TRY(fetch_words(e->h_ctr, 5, e->d_ctr.p + 5, 1, s));
 			HIP_TRY(hipStreamSynchronize(s));
 			sal_calls = e->h_ctr.p[5];
 		}
@@ -976,6 +1038,7 @@ extern "C" int cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *pa
 	if (!e || !par || !out || n_reads < 0 || (n_reads > 0 && !d_offsets) || (n_bases > 0 && !d_bases))
 		return fail(CS_EINVAL, "cs_engine_seed_batch_device: bad argument");
 	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
+	if (pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_seed_batch_device: submitted batches are in flight, collect them first");
 	HIP_TRY(hipSetDevice(e->device));
 	uint64_t nm = 0, ns = 0;
 	e->last.valid = false;
@@ -988,42 +1051,407 @@ extern "C" int cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *pa
 	return CS_OK;
 }
 
-extern "C" int cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases,
-                                    const uint64_t *offsets, cs_result_t *out)
+// ------------------------------------------------------------------------------------------------ the host variants
+// cs_engine_seed_batch_packed / cs_engine_seed_batch: the boundary the reference-side patch calls, i.e. the part
+// of the path the reference overlaps with kt_pipeline (main.cpp:438, cstl/kthread.c:121: read the next chunk / process / write).
+// The batch is cut into sub-batches; an upload thread stages sub-batch i+1 while the calling thread seeds sub-batch i, whose
+// results are packed on the device (16-byte mems, 8-byte seeds: include/compseed_amd.h) into one of two buffers and go to pinned
+// host memory on a copy stream of their own while sub-batch i+1 is seeded; cs_engine_seed_batch additionally expands finished
+// sub-batches to cs_intv_t / cs_seed_t on an expander thread (itself multi-threaded) beside all that.
+__global__ void pack_mems16_kernel(const OutMem *m, uint64_t n, uint4 *out)
 {
-	if (!e || !par || !out || n_reads < 0 || (n_reads > 0 && !offsets)) return fail(CS_EINVAL, "cs_engine_seed_batch: bad argument");
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const OutMem v = m[i];
+		const uint64_t beg = v.info >> 32, end = v.info & 0xffffffffull;
+		const uint64_t w0 = v.x0 | (v.x2 & 0x7fffffffull) << 33, w1 = v.x1 | beg << 33 | end << 48 | (v.x2 >> 31) << 63;
+		out[i] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+	}
+}
+__global__ void pack_rbeg_kernel(const OutSeed *sd, uint64_t n, int64_t *out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = sd[i].rbeg;
+}
+__global__ void shift_words_kernel(const uint64_t *in, uint64_t n, uint64_t add, uint64_t *out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[i] + add;
+}
+__global__ void rebase_words_kernel(uint64_t *io, uint64_t n)
+{
+	const uint64_t base = io[0]; // read by every thread before the grid-wide... single block: see launch
+	__syncthreads();
+	for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) io[i] -= base;
+}
+
+extern "C" int cs_host_alloc(size_t bytes, void **ptr)
+{
+	if (!ptr) return fail(CS_EINVAL, "null argument");
+	*ptr = nullptr;
+	HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+	return CS_OK;
+}
+extern "C" int cs_host_free(void *ptr)
+{
+	if (ptr) HIP_TRY(hipHostFree(ptr));
+	return CS_OK;
+}
+
+namespace {
+struct SubBatch { int64_t r0 = 0, n = 0; uint64_t b0 = 0, nb = 0, mem_base = 0, nm = 0, seed_base = 0, ns = 0; int slot = 0; };
+
+// expand packed sub-batch results into cs_intv_t / cs_seed_t arrays, `threads` workers over contiguous read ranges
+void expand_range(const cs_packed_result_t &P, cs_intv_t *mems, cs_seed_t *seeds, int64_t r0, int64_t r1)
+{
+	for (int64_t r = r0; r < r1; ++r) {
+		uint64_t sd = P.seed_off ? P.seed_off[r] : 0;
+		for (uint64_t m = P.mem_off[r]; m < P.mem_off[r + 1]; ++m) {
+			cs_intv_t v; cs_unpack_mem(&P, m, &v);
+			mems[m] = v;
+			if (P.seed_off) {
+				const int32_t qb = (int32_t)(v.info >> 32), ln = (int32_t)(uint32_t)v.info - qb;
+				const uint32_t c = cs_mem_seed_count(&v, P.max_occ);
+				for (uint32_t j = 0; j < c; ++j) { cs_seed_t x = {P.seed_rbeg[sd + j], qb, ln}; seeds[sd + j] = x; }
+				sd += c;
+			}
+		}
+	}
+}
+void expand_parallel(const cs_packed_result_t &P, cs_intv_t *mems, cs_seed_t *seeds, int64_t r0, int64_t r1, int threads)
+{
+	if (threads < 1) threads = 1;
+	if (r1 - r0 < 4096 || threads == 1) { expand_range(P, mems, seeds, r0, r1); return; }
+	std::vector<std::thread> th;
+	// equal shares of the MEMS, not of the reads: find read boundaries by bisection on mem_off
+	const uint64_t m0 = P.mem_off[r0], m1 = P.mem_off[r1];
+	int64_t prev = r0;
+	for (int t = 1; t <= threads; ++t) {
+		int64_t cut = r1;
+		if (t < threads) {
+			const uint64_t want = m0 + (m1 - m0) * (uint64_t)t / (uint64_t)threads;
+			cut = std::lower_bound(P.mem_off + r0, P.mem_off + r1, want) - P.mem_off;
+			if (cut < prev) cut = prev;
+		}
+		if (cut > prev) th.emplace_back(expand_range, std::cref(P), mems, seeds, prev, cut);
+		prev = cut;
+	}
+	for (auto &t : th) t.join();
+}
+} // namespace
+
+// ---- the engine's host pipeline: three threads behind cs_engine_submit / cs_engine_collect_packed
+//   upload thread   stages the parts (sub-batches) of submitted batches, in order, into one of two device input slots
+//   seeding thread  seeds a staged part (seed_device_impl), packs its results into one of two device pack slots and queues their
+//                   download into the batch's pinned result slot (one of two) on the copy stream
+//   expander thread (cs_engine_seed_batch only) expands downloaded parts into cs_intv_t / cs_seed_t arrays
+// so that, for a caller that keeps two batches submitted, the upload of batch n+1, the seeding of batch n and the download of
+// batch n-1 run at the same time -- what kt_pipeline (main.cpp:438) does for the reference's read / process / write steps.
+// All engine state touched by seed_device_impl belongs to the seeding thread while a batch is in flight: the blocking entry
+// points (device variant, digest, gather, primitives) refuse to run then.
+struct HostJob {
+	uint64_t batch = 0; int part = 0, n_parts = 0;
+	const uint8_t *bases = nullptr; const uint64_t *offsets = nullptr;
+	int64_t r0 = 0, n = 0, n_reads = 0; uint64_t b0 = 0, nb = 0;
+	cs_params_t par{}; bool pk16 = false, expand = false;
+	int in_slot = 0;
+};
+struct XJob { uint64_t batch; int64_t r0, n; uint64_t mem_base, nm, seed_base, ns; hipEvent_t ev; bool last; };
+struct BatchState {
+	uint64_t id = ~0ull; int64_t n_reads = 0; int parts_total = 0, parts_queued = 0; uint64_t mem_base = 0, seed_base = 0;
+	int rc = CS_OK; std::string err; bool pk16 = false, sal = false, expand = false, expanded = false; int max_occ = 0;
+};
+struct HostPipe {
+	std::thread th_up, th_seed, th_x;
+	std::mutex mu; std::condition_variable cv;
+	bool started = false, quit = false;
+	std::deque<HostJob> q_up, q_seed; std::deque<XJob> q_x; bool x_busy = false;
+	int in_free[2] = {1, 1};
+	uint64_t n_submitted = 0, n_collected = 0, parts_seen = 0;
+	long long handed = -1;               // batch whose pinned result slot the caller currently holds (until its next collect)
+	BatchState bs[2];
+};
+
+static void pipe_upload_thread(cs_engine *e)
+{
+	HostPipe &hp = *e->hp;
+	(void)hipSetDevice(e->device);
+	for (;;) {
+		HostJob j;
+		{
+			std::unique_lock<std::mutex> lk(hp.mu);
+			hp.cv.wait(lk, [&] { return hp.quit || (!hp.q_up.empty() && (hp.in_free[0] || hp.in_free[1])); });
+			if (hp.quit) return;
+			j = hp.q_up.front(); hp.q_up.pop_front();
+			j.in_slot = hp.in_free[0] ? 0 : 1; hp.in_free[j.in_slot] = 0;
+		}
+		hipError_t he = hipSuccess;
+		if (j.nb) he = hipMemcpyAsync(e->hp_in[j.in_slot].p, j.bases + j.b0, (size_t)j.nb, hipMemcpyHostToDevice, e->s_up);
+		if (he == hipSuccess && j.offsets) he = hipMemcpyAsync(e->hp_inoff[j.in_slot].p, j.offsets + j.r0, ((size_t)j.n + 1) * 8, hipMemcpyHostToDevice, e->s_up);
+		if (he == hipSuccess && j.offsets) { hipLaunchKernelGGL(rebase_words_kernel, dim3(1), dim3(1024), 0, e->s_up, e->hp_inoff[j.in_slot].p, (uint64_t)j.n + 1); he = hipGetLastError(); }
+		if (he == hipSuccess) he = hipStreamSynchronize(e->s_up);
+		std::lock_guard<std::mutex> lk(hp.mu);
+		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch & 1]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
+		hp.q_seed.push_back(j);
+		hp.cv.notify_all();
+	}
+}
+
+static void pipe_expand_thread(cs_engine *e)
+{
+	HostPipe &hp = *e->hp;
+	(void)hipSetDevice(e->device);
+	for (;;) {
+		XJob x;
+		{
+			std::unique_lock<std::mutex> lk(hp.mu);
+			hp.cv.wait(lk, [&] { return hp.quit || !hp.q_x.empty(); });
+			if (hp.quit) return;
+			x = hp.q_x.front(); hp.q_x.pop_front(); hp.x_busy = true;
+		}
+		BatchState &b = hp.bs[x.batch & 1];
+		const int rs = (int)(x.batch & 1);
+		bool ok = hipEventSynchronize(x.ev) == hipSuccess;
+		if (ok) {
+			const double scale = x.last ? 1.0 : (double)b.n_reads / (double)(x.r0 + x.n) * 1.08; // room for the whole batch at the first growth
+			ok = !e->x_mems.reserve((size_t)((double)(x.mem_base + x.nm) * scale) + 1, (size_t)x.mem_base) &&
+			     (!b.sal || !e->x_seeds.reserve((size_t)((double)(x.seed_base + x.ns) * scale) + 1, (size_t)x.seed_base));
+		}
+		if (ok) {
+			cs_packed_result_t Q; memset(&Q, 0, sizeof Q);
+			Q.n_reads = b.n_reads; Q.mem_format = b.pk16 ? CS_MEM_PACKED16 : CS_MEM_FULL32; Q.max_occ = b.max_occ;
+			Q.mem_off = e->hp_moff[rs].p; Q.mems = e->hp_mems[rs].p; Q.seed_off = b.sal ? e->hp_soff[rs].p : nullptr; Q.seed_rbeg = b.sal ? e->hp_rbeg[rs].p : nullptr;
+			expand_parallel(Q, e->x_mems.p, e->x_seeds.p, x.r0, x.r0 + x.n, e->opt.expand_threads);
+		}
+		std::lock_guard<std::mutex> lk(hp.mu);
+		if (!ok && b.rc == CS_OK) { b.rc = CS_ENOMEM; b.err = "expanding the packed results failed"; }
+		if (x.last) b.expanded = true;
+		hp.x_busy = false;
+		hp.cv.notify_all();
+	}
+}
+
+static void pipe_seed_thread(cs_engine *e)
+{
+	HostPipe &hp = *e->hp;
+	(void)hipSetDevice(e->device);
+	for (;;) {
+		HostJob j;
+		{
+			std::unique_lock<std::mutex> lk(hp.mu);
+			hp.cv.wait(lk, [&] { return hp.quit || !hp.q_seed.empty(); });
+			if (hp.quit) return;
+			j = hp.q_seed.front(); hp.q_seed.pop_front();
+		}
+		const int rs = (int)(j.batch & 1);
+		BatchState &b = hp.bs[rs];
+		int rc; { std::lock_guard<std::mutex> lk(hp.mu); rc = b.rc; }
+		std::string err;
+		auto hipf = [&](hipError_t he, const char *what) { if (he != hipSuccess && rc == CS_OK) { (void)hipGetLastError(); rc = he == hipErrorOutOfMemory ? CS_ENOMEM : CS_EDEVICE; err = std::string(what) + ": " + hipGetErrorString(he); } };
+		uint64_t nm = 0, ns = 0;
+		const bool sal = j.par.want_sal != 0;
+		const size_t msz = j.pk16 ? 16 : 32;
+		const auto t0 = std::chrono::steady_clock::now();
+		if (rc == CS_OK) { rc = seed_device_impl(e, &j.par, j.n, e->hp_in[j.in_slot].p, e->hp_inoff[j.in_slot].p, j.nb, &nm, &ns); if (rc != CS_OK) err = g_err; }
+		if (e->opt.verbose) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %lld reads seeded in %.1f ms\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (long long)j.n,
+		                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		{ std::lock_guard<std::mutex> lk(hp.mu); hp.in_free[j.in_slot] = 1; hp.cv.notify_all(); } // (the reads were converted into the engine's own buffer)
+		const uint64_t k = hp.parts_seen++;                 // running part number: pack slot k & 1, part events k % 4
+		const int ps = (int)(k & 1);
+		const uint64_t mem_base = b.mem_base, seed_base = b.seed_base;
+		if (rc == CS_OK) {
+			// the pack buffers of this slot were last used by the part before the previous one: its download must be over
+			if (k >= 2) hipf(hipEventSynchronize(e->hp_ev_dn[(k - 2) % 4]), "waiting for a download");
+			// the batch that used this pinned result slot before may still be in the caller's hands: wait until it is given back
+			{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || hp.handed < 0 || (uint64_t)hp.handed == j.batch || ((uint64_t)hp.handed & 1) != (j.batch & 1); }); if (hp.quit) return; }
+			// pinned room for the whole batch: estimated from its first part, grown (keeping what has arrived) if that was too little
+			const size_t need_m = (size_t)(mem_base + nm), need_s = (size_t)(seed_base + ns);
+			if (need_m * msz > e->hp_mems[rs].cap || (sal && need_s > e->hp_rbeg[rs].cap)) {
+				hipf(hipStreamSynchronize(e->s_down), "draining downloads before growing the result buffers");
+				{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || (hp.q_x.empty() && !hp.x_busy); }); if (hp.quit) return; } // the expander reads these buffers
+				const double scale = (double)j.n_reads / (double)(j.r0 + j.n) * 1.08;
+				if (rc == CS_OK && e->hp_mems[rs].reserve((size_t)((double)need_m * scale) * msz + 4096, true, (size_t)mem_base * msz) != CS_OK) { rc = CS_ENOMEM; err = g_err; }
+				if (rc == CS_OK && sal && e->hp_rbeg[rs].reserve((size_t)((double)need_s * scale) + 512, true, (size_t)seed_base) != CS_OK) { rc = CS_ENOMEM; err = g_err; }
+			}
+		}
+		if (rc == CS_OK && (e->hp_pk_mems[ps].reserve((size_t)nm * msz + 64) != CS_OK || (sal && e->hp_pk_rbeg[ps].reserve((size_t)ns + 8) != CS_OK))) { rc = CS_ENOMEM; err = g_err; }
+		if (rc == CS_OK) {
+			hipStream_t s = e->stream;
+			const unsigned g = (unsigned)e->n_cu * 8;
+			hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_mem_off.p, (uint64_t)j.n + 1, mem_base, e->hp_pk_moff[ps].p);
+			if (nm) {
+				if (j.pk16) hipLaunchKernelGGL(pack_mems16_kernel, dim3(g), dim3(256), 0, s, (const OutMem *)e->d_mems.p, nm, (uint4 *)e->hp_pk_mems[ps].p);
+				else hipf(hipMemcpyAsync(e->hp_pk_mems[ps].p, e->d_mems.p, (size_t)nm * 32, hipMemcpyDeviceToDevice, s), "copying mems");
+			}
+			if (sal) {
+				hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_seed_off.p, (uint64_t)j.n + 1, seed_base, e->hp_pk_soff[ps].p);
+				if (ns) hipLaunchKernelGGL(pack_rbeg_kernel, dim3(g), dim3(256), 0, s, (const OutSeed *)e->d_seeds.p, ns, e->hp_pk_rbeg[ps].p);
+			}
+			hipf(hipGetLastError(), "pack kernels");
+			hipf(hipEventRecord(e->hp_ev_pk[ps], s), "event");
+			hipf(hipStreamWaitEvent(e->s_down, e->hp_ev_pk[ps], 0), "event");
+			hipf(hipMemcpyAsync(e->hp_moff[rs].p + j.r0, e->hp_pk_moff[ps].p, ((size_t)j.n + 1) * 8, hipMemcpyDeviceToHost, e->s_down), "download");
+			if (nm) hipf(hipMemcpyAsync(e->hp_mems[rs].p + (size_t)mem_base * msz, e->hp_pk_mems[ps].p, (size_t)nm * msz, hipMemcpyDeviceToHost, e->s_down), "download");
+			if (sal) {
+				hipf(hipMemcpyAsync(e->hp_soff[rs].p + j.r0, e->hp_pk_soff[ps].p, ((size_t)j.n + 1) * 8, hipMemcpyDeviceToHost, e->s_down), "download");
+				if (ns) hipf(hipMemcpyAsync(e->hp_rbeg[rs].p + seed_base, e->hp_pk_rbeg[ps].p, (size_t)ns * 8, hipMemcpyDeviceToHost, e->s_down), "download");
+			}
+			hipf(hipEventRecord(e->hp_ev_dn[k % 4], e->s_down), "event");
+			if (j.part + 1 == j.n_parts) hipf(hipEventRecord(e->hp_ev_done[rs], e->s_down), "event");
+		}
+		std::lock_guard<std::mutex> lk(hp.mu);
+		if (rc != CS_OK && b.rc == CS_OK) { b.rc = rc; b.err = err; }
+		if (rc == CS_OK) {
+			b.mem_base += nm; b.seed_base += ns;
+			if (j.expand) { XJob x = {j.batch, j.r0, j.n, mem_base, nm, seed_base, ns, e->hp_ev_dn[k % 4], j.part + 1 == j.n_parts}; hp.q_x.push_back(x); }
+		}
+		b.parts_queued++;
+		hp.cv.notify_all();
+	}
+}
+
+static void pipe_stop(cs_engine *e)
+{
+	if (!e->hp) return;
+	HostPipe &hp = *e->hp;
+	{ std::lock_guard<std::mutex> lk(hp.mu); hp.quit = true; hp.cv.notify_all(); }
+	if (hp.th_up.joinable()) hp.th_up.join();
+	if (hp.th_seed.joinable()) hp.th_seed.join();
+	if (hp.th_x.joinable()) hp.th_x.join();
+	delete e->hp; e->hp = nullptr;
+}
+static bool pipe_busy(const cs_engine *e) { return e->hp && e->hp->n_submitted != e->hp->n_collected; }
+
+static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets, bool expand)
+{
+	if (!e || !par || n_reads < 0 || (n_reads > 0 && !offsets)) return fail(CS_EINVAL, "cs_engine_submit: bad argument");
 	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
+	if (par->min_seed_len < 1 || par->max_occ < 1 || par->split_width < 0) return fail(CS_EINVAL, "bad seeding parameters");
 	HIP_TRY(hipSetDevice(e->device));
-	hipStream_t s = e->stream;
-	uint64_t n_bases = 0;
+	if (!e->hp) e->hp = new HostPipe();
+	HostPipe &hp = *e->hp;
+	if (hp.n_submitted - hp.n_collected >= 2) return fail(CS_EINVAL, "cs_engine_submit: two batches are in flight already, collect one first");
+	uint64_t n_bases = 0, max_len = 0;
 	if (n_reads > 0) {
 		if (offsets[0] != 0) return fail(CS_EINVAL, "offsets[0] must be 0");
 		n_bases = offsets[n_reads];
 		if (n_bases > 0 && !bases) return fail(CS_EINVAL, "bases is null");
-		CS_TRY(e->d_raw.reserve((size_t)n_bases + 64));
-		CS_TRY(e->d_off.reserve((size_t)n_reads + 1));
-		HIP_TRY(hipMemcpyAsync(e->d_raw.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, s));
-		HIP_TRY(hipMemcpyAsync(e->d_off.p, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+		for (int64_t r = 0; r < n_reads; ++r) {
+			if (offsets[r + 1] < offsets[r]) return fail(CS_EINVAL, "offsets must start at 0, be non-decreasing and end at n_bases");
+			max_len = std::max(max_len, offsets[r + 1] - offsets[r]);
+		}
+		if (max_len >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
 	}
-	uint64_t nm = 0, ns = 0;
-	e->last.valid = false;
-	CS_TRY(seed_device_impl(e, par, n_reads, e->d_raw.p, e->d_off.p, n_bases, &nm, &ns));
-	e->last.valid = true; e->last.n_reads = n_reads; e->last.n_mems = nm; e->last.n_seeds = ns; e->last.want_sal = par->want_sal;
-	CS_TRY(e->h_mem_off.reserve((size_t)n_reads + 1));
-	CS_TRY(e->h_mems.reserve((size_t)nm + 1));
-	HIP_TRY(hipMemcpyAsync(e->h_mem_off.p, e->d_mem_off.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
-	if (nm) HIP_TRY(hipMemcpyAsync(e->h_mems.p, e->d_mems.p, (size_t)nm * sizeof(OutMem), hipMemcpyDeviceToHost, s));
-	if (par->want_sal) {
-		CS_TRY(e->h_seed_off.reserve((size_t)n_reads + 1));
-		CS_TRY(e->h_seeds.reserve((size_t)ns + 1));
-		HIP_TRY(hipMemcpyAsync(e->h_seed_off.p, e->d_seed_off.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
-		if (ns) HIP_TRY(hipMemcpyAsync(e->h_seeds.p, e->d_seeds.p, (size_t)ns * sizeof(OutSeed), hipMemcpyDeviceToHost, s));
+	const uint64_t id = hp.n_submitted;
+	const int rs = (int)(id & 1);
+	// parts: contiguous read ranges of about pipeline_reads reads (one, if the batch is not much larger than that)
+	std::vector<HostJob> parts;
+	const int64_t per = e->opt.pipeline_reads > 0 ? e->opt.pipeline_reads : std::max<int64_t>(n_reads, 1);
+	const int64_t kparts = std::max<int64_t>(1, (n_reads + per / 2) / per);
+	size_t in_cap = 0, off_cap = 0;
+	for (int64_t i = 0; i < kparts; ++i) {
+		HostJob j; j.batch = id; j.part = (int)i; j.n_parts = (int)kparts; j.bases = bases; j.offsets = offsets; j.n_reads = n_reads;
+		j.r0 = n_reads * i / kparts; j.n = n_reads * (i + 1) / kparts - j.r0;
+		j.b0 = n_reads ? offsets[j.r0] : 0; j.nb = n_reads ? offsets[j.r0 + j.n] - j.b0 : 0;
+		j.par = *par; j.pk16 = (e->ix.seq_len >> 33) == 0 && max_len < (1u << 15); j.expand = expand;
+		in_cap = std::max<size_t>(in_cap, j.nb); off_cap = std::max<size_t>(off_cap, (size_t)j.n + 1);
+		parts.push_back(j);
 	}
-	HIP_TRY(hipStreamSynchronize(s));
-	out->n_reads = n_reads; out->n_mems = nm; out->n_seeds = ns;
-	out->mem_off = e->h_mem_off.p; out->mems = (const cs_intv_t *)e->h_mems.p;
-	out->seed_off = par->want_sal ? e->h_seed_off.p : nullptr;
-	out->seeds = par->want_sal ? (const cs_seed_t *)e->h_seeds.p : nullptr;
+	{ // buffers the threads will use: sized here, while no part of this batch is in flight (earlier batches never need more than they have)
+		std::unique_lock<std::mutex> lk(hp.mu);
+		const bool idle = hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1];
+		if (in_cap + 64 > e->hp_in[0].cap || off_cap > e->hp_inoff[0].cap || off_cap > e->hp_pk_moff[0].cap || (par->want_sal && off_cap > e->hp_pk_soff[0].cap) ||
+		    (size_t)n_reads + 1 > e->hp_moff[rs].cap || (par->want_sal && (size_t)n_reads + 1 > e->hp_soff[rs].cap)) {
+			if (hp.handed >= 0 && ((uint64_t)hp.handed & 1) == (uint64_t)rs && ((size_t)n_reads + 1 > e->hp_moff[rs].cap || (par->want_sal && (size_t)n_reads + 1 > e->hp_soff[rs].cap)))
+				return fail(CS_EINVAL, "cs_engine_submit: this batch is larger than any before and its result slot is still in the caller's hands; collect first");
+			if (!idle) hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[rs ^ 1].parts_queued == hp.bs[rs ^ 1].parts_total); });
+			lk.unlock();
+			HIP_TRY(hipStreamSynchronize(e->s_down));
+			for (int k = 0; k < 2; ++k) {
+				CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
+				if (par->want_sal) CS_TRY(e->hp_pk_soff[k].reserve(off_cap));
+			}
+			CS_TRY(e->hp_moff[rs].reserve((size_t)n_reads + 1));
+			if (par->want_sal) CS_TRY(e->hp_soff[rs].reserve((size_t)n_reads + 1));
+			lk.lock();
+		}
+		BatchState &b = hp.bs[rs];
+		b = BatchState();
+		b.id = id; b.n_reads = n_reads; b.parts_total = (int)kparts; b.pk16 = parts[0].pk16; b.sal = par->want_sal != 0; b.expand = expand; b.max_occ = par->max_occ;
+		e->hp_moff[rs].p[0] = 0; if (b.sal) e->hp_soff[rs].p[0] = 0;
+		for (auto &j : parts) hp.q_up.push_back(j);
+		hp.n_submitted++;
+		e->last.valid = false;
+		if (!hp.started) {
+			hp.started = true;
+			hp.th_up = std::thread(pipe_upload_thread, e); hp.th_seed = std::thread(pipe_seed_thread, e); hp.th_x = std::thread(pipe_expand_thread, e);
+		}
+		hp.cv.notify_all();
+	}
+	return CS_OK;
+}
+
+static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
+{
+	if (!e || !out) return fail(CS_EINVAL, "cs_engine_collect: null argument");
+	if (!e->hp || e->hp->n_submitted == e->hp->n_collected) return fail(CS_EINVAL, "cs_engine_collect: nothing has been submitted");
+	HIP_TRY(hipSetDevice(e->device));
+	HostPipe &hp = *e->hp;
+	const uint64_t id = hp.n_collected;
+	const int rs = (int)(id & 1);
+	BatchState &b = hp.bs[rs];
+	{
+		std::unique_lock<std::mutex> lk(hp.mu);
+		hp.handed = -1;                      // the result handed out by the previous collect is given back: its slot may be overwritten
+		hp.cv.notify_all();
+		hp.cv.wait(lk, [&] { return b.parts_queued == b.parts_total; });
+	}
+	int rc = b.rc; std::string err = b.err;
+	if (rc == CS_OK && hipEventSynchronize(e->hp_ev_done[rs]) != hipSuccess) { rc = CS_EDEVICE; err = "waiting for the download"; (void)hipGetLastError(); }
+	if (rc == CS_OK && b.expand) {
+		std::unique_lock<std::mutex> lk(hp.mu);
+		hp.cv.wait(lk, [&] { return b.expanded || b.rc != CS_OK; });
+		rc = b.rc; err = b.err;
+	}
+	memset(out, 0, sizeof *out);
+	{
+		std::lock_guard<std::mutex> lk(hp.mu);
+		hp.n_collected++;
+		if (rc == CS_OK) hp.handed = (long long)id;
+	}
+	if (rc != CS_OK) return fail(rc, err);
+	out->n_reads = b.n_reads; out->n_mems = b.mem_base; out->n_seeds = b.seed_base; out->max_occ = b.max_occ;
+	out->mem_format = b.pk16 ? CS_MEM_PACKED16 : CS_MEM_FULL32;
+	out->mem_off = e->hp_moff[rs].p; out->mems = e->hp_mems[rs].p;
+	out->seed_off = b.sal ? e->hp_soff[rs].p : nullptr; out->seed_rbeg = b.sal ? e->hp_rbeg[rs].p : nullptr;
+	// cs_engine_result_digest / gather_reads work on the device-side result, which is the whole batch only if it was not cut
+	e->last.valid = b.parts_total == 1 && !pipe_busy(e); e->last.n_reads = b.n_reads; e->last.n_mems = b.mem_base; e->last.n_seeds = b.seed_base; e->last.want_sal = b.sal;
+	return CS_OK;
+}
+
+extern "C" int cs_engine_submit(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets)
+{
+	return pipe_submit(e, par, n_reads, bases, offsets, false);
+}
+extern "C" int cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out) { return pipe_collect(e, out); }
+
+extern "C" int cs_engine_seed_batch_packed(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases,
+                                           const uint64_t *offsets, cs_packed_result_t *out)
+{
+	if (!e || !par || !out) return fail(CS_EINVAL, "cs_engine_seed_batch_packed: bad argument");
+	if (pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_seed_batch_packed: submitted batches are in flight, collect them first");
+	CS_TRY(pipe_submit(e, par, n_reads, bases, offsets, false));
+	return pipe_collect(e, out);
+}
+
+extern "C" int cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases,
+                                    const uint64_t *offsets, cs_result_t *out)
+{
+	if (!e || !par || !out) return fail(CS_EINVAL, "cs_engine_seed_batch: bad argument");
+	if (pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_seed_batch: submitted batches are in flight, collect them first");
+	CS_TRY(pipe_submit(e, par, n_reads, bases, offsets, true));
+	cs_packed_result_t P;
+	CS_TRY(pipe_collect(e, &P));
+	out->n_reads = n_reads; out->n_mems = P.n_mems; out->n_seeds = P.n_seeds;
+	out->mem_off = P.mem_off; out->mems = e->x_mems.p;
+	out->seed_off = P.seed_off; out->seeds = par->want_sal ? e->x_seeds.p : nullptr;
 	return CS_OK;
 }
 
@@ -1043,7 +1471,7 @@ __global__ void digest_kernel(const uint64_t *w, uint64_t n, unsigned long long 
 extern "C" int cs_engine_result_digest(cs_engine_t *e, cs_digest_t *out)
 {
 	if (!e || !out) return fail(CS_EINVAL, "null argument");
-	if (!e->last.valid) return fail(CS_EINVAL, "cs_engine_result_digest: no result held (call a seed function first)");
+	if (!e->last.valid || pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_result_digest: no whole-batch result is held on the device (call a seed function first)");
 	HIP_TRY(hipSetDevice(e->device));
 	hipStream_t s = e->stream;
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 4 * sizeof(unsigned long long), s));
@@ -1087,7 +1515,7 @@ __global__ void sel_copy_kernel(const uint64_t *ids, int64_t n_sel, const uint64
 extern "C" int cs_engine_gather_reads(cs_engine_t *e, int64_t n_sel, const uint64_t *read_ids, cs_result_t *out)
 {
 	if (!e || !out || n_sel < 0 || (n_sel > 0 && !read_ids)) return fail(CS_EINVAL, "cs_engine_gather_reads: bad argument");
-	if (!e->last.valid) return fail(CS_EINVAL, "cs_engine_gather_reads: no result held (call a seed function first)");
+	if (!e->last.valid || pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_gather_reads: no whole-batch result is held on the device (call a seed function first)");
 	HIP_TRY(hipSetDevice(e->device));
 	hipStream_t s = e->stream;
 	const bool sal = e->last.want_sal != 0;

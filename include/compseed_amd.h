@@ -92,10 +92,13 @@ typedef struct {
 	int64_t lep_arena_mb;     /* [32768] arena of the forward passes' left-extension points; smaller = more chunks per pass   */
 	int64_t max_raw_mb;       /* [24576] first-pass mem arena; smaller = a batch is processed in more sub-batches             */
 	int32_t r3_text_iter;     /* [4] forward launch after which round 3 starts on its side stream                             */
+	int32_t pipeline_reads;   /* [5000000] reads per sub-batch of the host variants (cs_engine_seed_batch, _packed): upload of the next,
+	                           *     seeding of the current and download of the previous sub-batch overlap; 0 = the whole batch at once */
+	int32_t expand_threads;   /* [16] host threads that expand packed results in cs_engine_seed_batch                         */
 	int32_t count_sal_merged; /* [0] 1: also count the distinct SA slots per 512 reads (cs_stats_t.sal_calls as the reference
 	                           *     counts them, comp_seed.cpp:2327-2345); costs one sort of the slots per call              */
 	int32_t verbose;          /* [0] progress lines on stderr                                                                 */
-	int32_t reserved[7];      /* must be 0 */
+	int32_t reserved[5];      /* must be 0 */
 } cs_engine_options_t;
 
 /* CSR result of one batch.  Read r owns mems[mem_off[r] .. mem_off[r+1]) sorted by info (comp_seed.cpp:2301) and
@@ -177,6 +180,55 @@ int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_read
                           const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
 int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                                  const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases, cs_result_t *out);
+
+/* ---- packed results: what actually crosses PCIe.  A 10 M-read batch produces ~80 M mems and ~200 M seeds, 5.9 GB as cs_intv_t /
+ *      cs_seed_t -- more transfer time than seeding time -- but half of those bytes are implied: a seed's qbeg and len are its
+ *      mem's, a mem's seeds are its first min(x2, max_occ) slots (comp_seed.cpp:2313-2325), and three 33-bit coordinates, a 32-bit
+ *      size and two 15-bit query positions fit 16 bytes.  cs_engine_seed_batch_packed returns that form in pinned host memory;
+ *      a consumer that copies per read anyway (the reference does: aux.match[r] / aux.seed[r] are per-read vectors) unpacks on
+ *      the fly in its own worker threads with the inline helpers below, and cs_engine_seed_batch is this call followed by a
+ *      multi-threaded expansion into cs_intv_t / cs_seed_t arrays.  Both split the batch into sub-batches and overlap the upload
+ *      of the next, the seeding of the current and the download (and expansion) of the previous one.
+ *      mem_format CS_MEM_PACKED16 needs an index shorter than 2^33 symbols and reads shorter than 2^15 bases (hg19 / T2T, short
+ *      reads); anything else comes back as CS_MEM_FULL32 (plain cs_intv_t), seeds as rbeg either way. */
+#define CS_MEM_FULL32   0
+#define CS_MEM_PACKED16 1
+typedef struct { uint64_t w0, w1; } cs_mem16_t;
+/* w0 = x0 | (x2 & 0x7fffffff) << 33;   w1 = x1 | beg << 33 | end << 48 | (x2 >> 31) << 63 */
+typedef struct {
+	int64_t   n_reads;
+	uint64_t  n_mems, n_seeds;
+	int32_t   mem_format;        /* CS_MEM_PACKED16 or CS_MEM_FULL32 */
+	int32_t   max_occ;           /* the -c the batch was seeded with: a mem owns min(x2, max_occ) consecutive entries of seed_rbeg */
+	const uint64_t *mem_off;     /* n_reads + 1 */
+	const void     *mems;        /* cs_mem16_t[n_mems] or cs_intv_t[n_mems] */
+	const uint64_t *seed_off;    /* n_reads + 1, NULL when want_sal == 0 */
+	const int64_t  *seed_rbeg;   /* n_seeds, in mem-then-slot order */
+} cs_packed_result_t;
+int  cs_engine_seed_batch_packed(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
+                                 const uint8_t *bases, const uint64_t *offsets, cs_packed_result_t *out);
+/* The same as a two-deep pipeline across batches, the counterpart of the reference's kt_pipeline (main.cpp:438: read chunk n+1 while
+ * chunk n is processed and chunk n-1 written): cs_engine_submit queues a batch and returns at once (at most two in flight; the caller's
+ * buffers must stay untouched until the batch is collected), cs_engine_collect_packed blocks until the OLDEST submitted batch is complete.
+ * With two batches kept submitted the upload of batch n+1, the seeding of batch n and the download of batch n-1 overlap, and throughput is
+ * that of the slowest of the three instead of their sum.  A collected result stays valid until the next collect or blocking seed call.
+ * While batches are in flight the engine's other entry points that use the device return CS_EINVAL. */
+int  cs_engine_submit(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets);
+int  cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out);
+static inline void cs_unpack_mem(const cs_packed_result_t *r, uint64_t i, cs_intv_t *m)
+{
+	if (r->mem_format == CS_MEM_PACKED16) {
+		const cs_mem16_t p = ((const cs_mem16_t *)r->mems)[i];
+		m->x0 = p.w0 & 0x1ffffffffull; m->x1 = p.w1 & 0x1ffffffffull;
+		m->x2 = (p.w0 >> 33) | ((p.w1 >> 63) << 31);
+		m->info = ((p.w1 >> 33) & 0x7fffull) << 32 | ((p.w1 >> 48) & 0x7fffull);
+	} else *m = ((const cs_intv_t *)r->mems)[i];
+}
+static inline uint32_t cs_mem_seed_count(const cs_intv_t *m, int32_t max_occ) { return m->x2 < (uint64_t)max_occ ? (uint32_t)m->x2 : (uint32_t)max_occ; }
+/* pinned host memory for the caller's read chunk (uploads from it are asynchronous and run at link speed; pageable memory works
+ * too, through a staging thread) */
+int  cs_host_alloc(size_t bytes, void **ptr);
+int  cs_host_free(void *ptr);
 
 /* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array
  *      (sum over the array's 64-bit words w[i] of splitmix64(w[i] + i * 0x9E3779B97F4A7C15), mod 2^64), so that two runs over

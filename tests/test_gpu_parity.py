@@ -404,3 +404,102 @@ def test_config1_ecoli_size_set_on_the_gpu():
             if sst == 0:
                 assert st["bwt_queries"] == w["bwt_queries"] == 38109585
     e.close(); ix.close()
+
+
+def _expand_packed(p):
+    """host restatement of what cs_engine_seed_batch does with the packed form (and what a consumer does with cs_unpack_mem)"""
+    import compseed_amd as ca
+    mems = ca.unpack_mems16(p["mems"]) if p["mem_format"] == 1 else p["mems"].copy()
+    if p["seed_off"] is None:
+        return mems, None
+    cnt = np.minimum(mems["x2"], np.uint64(p["max_occ"])).astype(np.int64)
+    seeds = np.zeros(p["n_seeds"], dtype=ca.SEED_DT)
+    seeds["rbeg"] = p["seed_rbeg"]
+    seeds["qbeg"] = np.repeat((mems["info"] >> np.uint64(32)).astype(np.int32), cnt)
+    seeds["len"] = np.repeat(((mems["info"] & np.uint64(0xffffffff)) - (mems["info"] >> np.uint64(32))).astype(np.int32), cnt)
+    return mems, seeds
+
+
+@pytest.mark.parametrize("pipeline_reads", [0, 700, 64])
+def test_packed_and_pipelined_host_variants(pipeline_reads):
+    """cs_engine_seed_batch_packed (16-byte mems, seeds as rbeg) and cs_engine_seed_batch (the same, expanded on host threads), cut into
+    sub-batches of `pipeline_reads` reads whose upload / seeding / download overlap: every golden run, bit for bit, from pageable and
+    from pinned input (cs_host_alloc)"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0, pipeline_reads=pipeline_reads, expand_threads=3)
+    for name, pname in _data.golden_runs():
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        _check_against_golden(e.seed_batch(bases, off, ca.Params(**kw)), z)
+        pin = ca.pinned_array(max(1, bases.size))
+        pin[:bases.size] = bases
+        p = e.seed_batch_packed(pin, off, ca.Params(**kw))
+        assert p["mem_format"] == 1 and p["mems"].dtype.itemsize == 16
+        mems, seeds = _expand_packed(p)
+        assert np.array_equal(p["mem_off"], z["mem_off"]) and np.array_equal(p["seed_off"], z["seed_off"])
+        assert np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), z["mems"])
+        assert np.array_equal(seeds["rbeg"], z["seed_rbeg"]) and np.array_equal(seeds["qbeg"], z["seed_qbeg"]) and np.array_equal(seeds["len"], z["seed_len"])
+        nos = e.seed_batch_packed(bases, off, ca.Params(want_sal=0, **kw))
+        assert nos["seed_off"] is None and nos["n_seeds"] == 0 and np.array_equal(ca.unpack_mems16(nos["mems"]), mems)
+        r0 = e.seed_batch(bases, off, ca.Params(want_sal=0, **kw))
+        assert r0.seeds is None and np.array_equal(r0.mems, mems)
+    e.close(); ix.close()
+
+
+def test_packed_falls_back_to_full_records_for_long_reads(eng):
+    """reads of 2^15 bases or more do not fit the 15-bit query fields of cs_mem16_t: the packed call returns plain cs_intv_t records"""
+    import compseed_amd as ca
+    import gzip
+    fa = gzip.open(os.path.join(_data.GOLD, "ref.fa.gz")).read().decode().split("\n")
+    g = "".join(l for l in fa if not l.startswith(">")).replace("N", "A")
+    bases, off = _data.pack_reads([g[1000:41000].encode(), g[50000:50150].encode()])
+    p = eng.seed_batch_packed(bases, off)
+    assert p["mem_format"] == 0 and p["mems"].dtype == ca.INTV_DT
+    full = eng.seed_batch(bases, off)
+    assert np.array_equal(p["mems"], full.mems) and np.array_equal(p["seed_rbeg"], full.seeds["rbeg"]) and np.array_equal(p["mem_off"], full.mem_off)
+    o = _oracle.OracleIndex(_data.PREFIX)
+    want = o.seed_batch(bases, off, mode=0, threads=2)
+    assert np.array_equal(full.mems, want["mems"]) and np.array_equal(full.seeds, want["seeds"])
+    o.close()
+
+
+def test_submit_collect_pipeline_across_batches():
+    """cs_engine_submit / cs_engine_collect_packed: two batches in flight, results come back in submission order and equal the goldens;
+    a collected result stays intact while later batches are submitted, seeded and downloaded; misuse is an error code"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0, pipeline_reads=900)
+    runs = [("main100", "default"), ("sorted150", "default"), ("repeat100", "default"), ("ragged", "default"), ("main100", "default"), ("shuffled100", "default")]
+    data = []
+    for name, pname in runs:
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        pin = ca.pinned_array(max(1, bases.size)); pin[:bases.size] = bases
+        data.append((z, pin, off))
+    with pytest.raises(ca.CSError):
+        e.collect_packed()                                   # nothing submitted
+    e.submit(data[0][1], data[0][2]); e.submit(data[1][1], data[1][2])
+    with pytest.raises(ca.CSError):
+        e.submit(data[2][1], data[2][2])                     # two in flight already
+    with pytest.raises(ca.CSError):
+        e.seed_batch(data[2][1], data[2][2])                 # blocking calls refuse while batches are in flight
+    held = None
+    for i in range(len(runs)):
+        p = e.collect_packed()
+        if held is not None:                                 # (the previous result was valid until this collect: checked below before it)
+            pass
+        z = data[i][0]
+        mems, seeds = _expand_packed(p)
+        assert np.array_equal(p["mem_off"], z["mem_off"]) and np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), z["mems"]), runs[i]
+        assert np.array_equal(seeds["rbeg"], z["seed_rbeg"]) and np.array_equal(p["seed_off"], z["seed_off"]), runs[i]
+        if i + 2 < len(runs):
+            e.submit(data[i + 2][1], data[i + 2][2])         # keep two in flight
+            import time
+            time.sleep(0.05)                                 # let the next batches run: the held result must not change under us
+            m2, s2 = _expand_packed(p)
+            assert np.array_equal(m2, mems) and np.array_equal(s2["rbeg"], seeds["rbeg"])
+        held = p
+    got = e.seed_batch(data[0][1], data[0][2])               # and the blocking calls work again afterwards
+    _check_against_golden(got, data[0][0])
+    e.close(); ix.close()

@@ -111,6 +111,12 @@ def test_invariance_under_batching_sst_and_kernel_variant(world):
     p1 = eng.seed_batch(hb[: cut * 150], ho[: cut + 1])
     p2 = eng.seed_batch(hb[cut * 150:], ho[cut:] - ho[cut])
     assert np.array_equal(np.concatenate([p1.mems, p2.mems]), res.mems) and np.array_equal(np.concatenate([p1.seeds, p2.seeds]), res.seeds)
+    e3 = ca.Engine(world["ix"], 0, pipeline_reads=90_000, expand_threads=4)  # the host pipeline: 4 sub-batches, unequal tails
+    pp = e3.seed_batch(hb, ho)
+    assert np.array_equal(pp.mem_off, res.mem_off) and np.array_equal(pp.mems, res.mems) and np.array_equal(pp.seed_off, res.seed_off) and np.array_equal(pp.seeds, res.seeds)
+    pk = e3.seed_batch_packed(hb, ho)
+    assert pk["n_mems"] == res.n_mems and np.array_equal(ca.unpack_mems16(pk["mems"]), res.mems) and np.array_equal(pk["seed_rbeg"], res.seeds["rbeg"])
+    e3.close()
     e2 = ca.Engine(world["ix"], 0, fused=1)                                 # second, independent implementation
     f = e2.seed_batch(hb[: 60000 * 150], ho[: 60001])
     e2.close()
