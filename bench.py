@@ -68,6 +68,11 @@ def parse_args():
                     help="live: HBM bytes of the SMEM stage from a rocprofv3 --pmc FETCH_SIZE child run of this script (N = 1 only)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: the profiled child of --traffic live
     ap.add_argument("--lib", default="", help="alternative build of libcompseed_amd.so (A/B experiments)")
+    ap.add_argument("--index-broadcast", action="store_true",
+                    help="N > 1: rank 0 builds the index and broadcasts it over RCCL instead of every rank building its own replica")
+    ap.add_argument("--ingest-rank0", action="store_true",
+                    help="after the timed region also time the north_star's data movement: rank 0 holds the whole chunk (N x --reads reads), "
+                         "scatters contiguous read ranges over RCCL, every rank seeds its range, rank 0 gathers mems and seeds")
     ap.add_argument("-k", type=int, default=19); ap.add_argument("-r", type=float, default=1.5)
     ap.add_argument("-y", type=int, default=20); ap.add_argument("-c", type=int, default=500); ap.add_argument("-s", type=int, default=10)
     return ap.parse_args()
@@ -191,7 +196,23 @@ def main():
     torch.cuda.synchronize()
     t1 = time.time()
     torch.cuda.empty_cache()
-    ix = ca.Index.build(g_host, local)
+    from compseed_amd.sharding import Collectives, device_tensor_view
+    coll = Collectives(D, dev)
+    if args.index_broadcast and world > 1:  # one build, then the arrays travel over xGMI
+        arrays = None
+        if rank == 0:
+            ix0 = ca.Index.build(g_host, local)
+            bw0, sa0 = ix0.arrays()
+            arrays = dict(primary=ix0.view.primary, L2=[ix0.view.L2[i] for i in range(1, 5)], bwt=bw0, sa=sa0, sa_intv=32)
+        tb = time.time()
+        arrays = coll.broadcast_index(arrays)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log("index broadcast to %d ranks: %.2f s for %.2f GB" % (world, time.time() - tb, (arrays["bwt"].nbytes + arrays["sa"].nbytes) / 1e9))
+        ix = ix0 if rank == 0 else ca.Index.from_arrays(arrays["primary"], arrays["L2"], arrays["bwt"], arrays["sa"], arrays["sa_intv"])
+        torch.cuda.empty_cache()
+    else:
+        ix = ca.Index.build(g_host, local)
     del g_host
     t2 = time.time()
     eopts = {}
@@ -421,7 +442,41 @@ def main():
         if not all_ok:
             out["value"] = None
             out["error"] = "results differ from the oracle: the throughput above is void"
-        print(json.dumps(out), flush=True)
+    if args.ingest_rank0:
+        # ---- the north_star's data movement, timed on its own (never `value`): rank 0 owns the chunk (it is the ingest rank: it read the
+        # file), contiguous read ranges go out over RCCL, every rank seeds its range on its resident replica, mems and seeds come back
+        big = None
+        if rank == 0:
+            parts = [bases] + [torch.empty_like(bases) for _ in range(world - 1)]
+            for g in range(1, world):
+                parts[g].copy_(bases)                 # (the same reads again: the payload size is what matters here)
+            big_b = torch.cat(parts); del parts
+            big_o = torch.arange(args.reads * world + 1, dtype=torch.int64, device=dev) * args.read_len
+            big = (big_b, big_o)
+        D.barrier(); t_a = time.perf_counter()
+        mb, mo = coll.scatter_reads(big[0] if big else None, big[1] if big else None)
+        torch.cuda.synchronize(); D.barrier(); t_b = time.perf_counter()
+        r2 = eng.seed_batch_device(mb.data_ptr(), mo.data_ptr(), mo.numel() - 1, mb.numel(), par)
+        D.barrier(); t_c = time.perf_counter()
+        v64 = lambda ptr, nbytes: device_tensor_view(ptr, nbytes, dev).view(torch.int64)
+        sal_on = not args.no_sal
+        g_ = coll.gather_results(v64(r2.ptr["mem_off"], (r2.n_reads + 1) * 8), v64(r2.ptr["mems"], r2.n_mems * 32),
+                               v64(r2.ptr["seed_off"], (r2.n_reads + 1) * 8) if sal_on else None, v64(r2.ptr["seeds"], r2.n_seeds * 16) if sal_on else None)
+        torch.cuda.synchronize(); D.barrier(); t_d = time.perf_counter()
+        if rank == 0:
+            tot = args.reads * world
+            ok_g = int(g_["mem_off"][-1]) * 4 == g_["mems"].numel() and g_["mem_off"].numel() == tot + 1
+            # rank 0's own share must come back unchanged at the front of the gathered arrays
+            ok_g = ok_g and bool(torch.equal(g_["mems"][: r2.n_mems * 4], v64(r2.ptr["mems"], r2.n_mems * 32)))
+            out_ing = {"reads": tot, "reads_per_s": tot / (t_d - t_a), "scatter_ms": 1e3 * (t_b - t_a), "seed_ms": 1e3 * (t_c - t_b), "gather_ms": 1e3 * (t_d - t_c),
+                       "scatter_bytes": int(big[0].numel() + big[1].numel() * 8), "gather_bytes": int(sum(t.numel() for t in g_.values() if t is not None) * 8),
+                       "consistent": bool(ok_g),
+                       "note": "rank 0 holds the chunk; two-phase scatter of read ranges, seeding of every range on its rank, two-phase gather of mems and seeds "
+                               "to rank 0, all over torch.distributed / RCCL, nothing overlapped"}
+            out["ingest_rank0"] = out_ing
+        del big, g_
+    if rank == 0:
+        print(json.dumps(out), flush=True)   # the ONE line
     oidx.close()
     D.close()
     eng.close(); ix.close()
