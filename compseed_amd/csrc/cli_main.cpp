@@ -64,6 +64,7 @@ static void usage()
 
 int main(int argc, char **argv)
 {
+	setenv("GPU_MAX_HW_QUEUES", "8", 0); // before the HIP runtime starts: one engine per GPU, each with streams of its own
 	cs_params_t par; cs_params_default(&par);
 	int n_threads = 1, n_gpus = -1, verbose = 0; long fixed_chunk = 0; const char *dump = nullptr;
 	std::vector<const char *> pos;

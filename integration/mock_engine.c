@@ -1,0 +1,77 @@
+/* integration/mock_engine.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A stand-in for libcompseed_amd.so that implements, on the CPU and on top of the oracle (oracle/cs_oracle.c), exactly the entry
+ * points integration/compseed_gpu.patch calls -- so that the PATCHED reference can be run end to end in the build container, which
+ * has no GPU, and its SAM output compared with the unpatched reference's: that proves the reference-side binding (chunk packing,
+ * submit in the reader step / collect in the worker step, cs_unpack_mem, seeds in mem-then-slot order) without the device.
+ * The real library's results are compared with the same oracle on the GPU box (tests/test_gpu_*.py).  Never shipped, never linked
+ * into the product. */
+#include "compseed_amd.h"
+#include "../oracle/cs_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+struct cs_engine {
+	cso_index_t ix;
+	struct { cs_params_t par; int64_t n; const uint8_t *bases; const uint64_t *off; } q[2];
+	uint64_t n_sub, n_col;
+	struct { uint64_t *mem_off, *seed_off; cs_mem16_t *mems; int64_t *rbeg; } res[2];
+	cs_stats_t st;
+};
+static const char *g_err = "";
+const char *cs_last_error(void) { return g_err; }
+void cs_params_default(cs_params_t *p)
+{
+	memset(p, 0, sizeof *p);
+	p->min_seed_len = 19; p->split_factor = 1.5f; p->split_width = 10; p->max_occ = 500; p->max_mem_intv = 20; p->want_sal = 1; p->sst_mode = 1;
+}
+int cs_host_alloc(size_t bytes, void **ptr) { *ptr = malloc(bytes ? bytes : 1); return *ptr ? CS_OK : CS_ENOMEM; }
+int cs_host_free(void *ptr) { free(ptr); return CS_OK; }
+int cs_engine_create(const cs_index_view_t *v, int device, cs_engine_t **out)
+{
+	(void)device;
+	cs_engine_t *e = (cs_engine_t *)calloc(1, sizeof *e);
+	if (!e) return CS_ENOMEM;
+	cso_index_wrap(&e->ix, v->primary, &v->L2[1], v->bwt, v->bwt_size, v->sa, v->n_sa, v->sa_intv);
+	*out = e;
+	return CS_OK;
+}
+void cs_engine_destroy(cs_engine_t *e)
+{
+	if (!e) return;
+	for (int k = 0; k < 2; ++k) { free(e->res[k].mem_off); free(e->res[k].seed_off); free(e->res[k].mems); free(e->res[k].rbeg); }
+	free(e);
+}
+int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st) { *st = e->st; return CS_OK; }
+int cs_engine_submit(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets)
+{
+	if (e->n_sub - e->n_col >= 2) { g_err = "two batches are in flight already"; return CS_EINVAL; }
+	int k = (int)(e->n_sub++ & 1);
+	e->q[k].par = *par; e->q[k].n = n_reads; e->q[k].bases = bases; e->q[k].off = offsets;
+	return CS_OK;
+}
+int cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out)
+{
+	if (e->n_sub == e->n_col) { g_err = "nothing has been submitted"; return CS_EINVAL; }
+	int k = (int)(e->n_col++ & 1);
+	cso_params_t op = {e->q[k].par.min_seed_len, e->q[k].par.split_factor, e->q[k].par.split_width, e->q[k].par.max_occ, e->q[k].par.max_mem_intv};
+	uint64_t *mo = NULL, *so = NULL; cso_intv_t *mm = NULL; cso_seed_t *ss = NULL; cso_stats_t st;
+	if (cso_seed_batch(&e->ix, &op, e->q[k].n, e->q[k].bases, e->q[k].off, 1, 512, 1, 4, &mo, &mm, &so, &ss, &st)) { g_err = "oracle failed"; return CS_EDEVICE; }
+	free(e->res[k].mem_off); free(e->res[k].seed_off); free(e->res[k].mems); free(e->res[k].rbeg);
+	e->res[k].mem_off = mo; e->res[k].seed_off = so;
+	e->res[k].mems = (cs_mem16_t *)malloc((st.n_mems + 1) * sizeof(cs_mem16_t));
+	e->res[k].rbeg = (int64_t *)malloc((st.n_seeds + 1) * sizeof(int64_t));
+	for (uint64_t i = 0; i < st.n_mems; ++i) { /* the packing of include/compseed_amd.h (CS_MEM_PACKED16) */
+		uint64_t beg = mm[i].info >> 32, end = mm[i].info & 0xffffffffull;
+		e->res[k].mems[i].w0 = mm[i].x0 | (mm[i].x2 & 0x7fffffffull) << 33;
+		e->res[k].mems[i].w1 = mm[i].x1 | beg << 33 | end << 48 | (mm[i].x2 >> 31) << 63;
+	}
+	for (uint64_t i = 0; i < st.n_seeds; ++i) e->res[k].rbeg[i] = ss[i].rbeg;
+	cso_free(mm); cso_free(ss);
+	memset(out, 0, sizeof *out);
+	out->n_reads = e->q[k].n; out->n_mems = st.n_mems; out->n_seeds = st.n_seeds; out->mem_format = CS_MEM_PACKED16; out->max_occ = e->q[k].par.max_occ;
+	out->mem_off = e->res[k].mem_off; out->mems = e->res[k].mems; out->seed_off = e->res[k].seed_off; out->seed_rbeg = e->res[k].rbeg;
+	e->st.reads += (uint64_t)e->q[k].n; e->st.mems += st.n_mems; e->st.seeds += st.n_seeds; e->st.bwt_queries += st.bwt_queries; e->st.bwt_calls += st.bwt_calls;
+	return CS_OK;
+}
