@@ -11,7 +11,7 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 
 # every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
-           "cs_index_build_flags", "cs_index_save",
+           "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
@@ -174,6 +174,12 @@ def load_library():
     L.cs_engine_options_default.restype = None
     L.cs_engine_create_opts.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(EngineOptions), C.POINTER(vp)]
     L.cs_index_save.argtypes = [vp, C.c_char_p]
+    L.cs_refseq_from_fasta.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.cs_refseq_codes.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.cs_refseq_save.argtypes = [vp, C.c_char_p]
+    L.cs_refseq_free.argtypes = [vp]
+    L.cs_refseq_free.restype = None
+    L.cs_index_build_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
     L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
     L.cs_engine_destroy.argtypes = [vp]
@@ -279,6 +285,38 @@ class Index:
             self.close()
         except Exception:
             pass
+
+
+class RefSeq:
+    """reference sequences from a FASTA (cs_refseq_t): contig table, holes, forward strand as codes 0..3"""
+
+    def __init__(self, fasta):
+        self._h = C.c_void_p()
+        _check(load_library().cs_refseq_from_fasta(os.fsencode(fasta), C.byref(self._h)))
+        p, n, ns, nh = C.c_void_p(), C.c_uint64(), C.c_int32(), C.c_int32()
+        _check(load_library().cs_refseq_codes(self._h, C.byref(p), C.byref(n), C.byref(ns), C.byref(nh)))
+        self.l_pac, self.n_seqs, self.n_holes = int(n.value), int(ns.value), int(nh.value)
+        self.codes = _view(p.value, np.uint8, self.l_pac)
+
+    def save(self, prefix):
+        """<prefix>.pac / .ann / .amb as bwaidx writes them"""
+        _check(load_library().cs_refseq_save(self._h, os.fsencode(prefix)))
+
+    def close(self):
+        if self._h:
+            load_library().cs_refseq_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_index_from_fasta(fasta, prefix, device=0):
+    """bwa_idx_build: all five index files from a FASTA, the suffix sort on the GPU (cs_index_build_fasta)"""
+    _check(load_library().cs_index_build_fasta(os.fsencode(fasta), os.fsencode(prefix), int(device)))
 
 
 class Result:

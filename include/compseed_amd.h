@@ -162,6 +162,18 @@ int  cs_index_build(const uint8_t *fwd_nt4, uint64_t l_pac, int device, cs_index
 int  cs_index_build_flags(const uint8_t *fwd_nt4, uint64_t l_pac, int device, uint32_t flags, cs_index_t **out);
 int  cs_index_save(const cs_index_t *idx, const char *prefix);
 
+/* ---- reference sequences: the FASTA front end of the builder and the other three index files.  cs_refseq_from_fasta reads FASTA / FASTQ
+ *      (plain or gzip) as bns_fasta2bntseq does (FM_index/bntseq.c:280-330): contig table, holes (runs of one ambiguity code), and the
+ *      forward strand as codes 0..3 with every ambiguous base replaced by lrand48() & 3 after srand48(11) (bntseq.c:266,295);
+ *      cs_refseq_save writes <prefix>.pac / .ann / .amb byte-identical to bwaidx (bns_dump, bntseq.c:65-95);
+ *      cs_index_build_fasta is bwa_idx_build (index_main.c:257-325): all five files from a FASTA, the suffix sort on the GPU. */
+typedef struct cs_refseq cs_refseq_t;
+int  cs_refseq_from_fasta(const char *path, cs_refseq_t **out);
+int  cs_refseq_codes(const cs_refseq_t *r, const uint8_t **fwd_nt4, uint64_t *l_pac, int32_t *n_seqs, int32_t *n_holes);
+int  cs_refseq_save(const cs_refseq_t *r, const char *prefix);
+void cs_refseq_free(cs_refseq_t *r);
+int  cs_index_build_fasta(const char *fasta, const char *prefix, int device);
+
 /* ---- engine: uploads the index to GPU `device` once (replaces bwa_idx_load_from_shm's role: HBM residency) */
 int  cs_device_count(int *n);
 void cs_engine_options_default(cs_engine_options_t *o);

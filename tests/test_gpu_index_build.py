@@ -78,3 +78,14 @@ def test_64bit_builder_instantiation(tmp_path):
     bwt, sa = ix.arrays()
     assert ix.view.primary == f["primary"] and np.array_equal(bwt, f["bwt"]) and np.array_equal(sa, f["sa"])
     ix.close()
+
+
+def test_index_from_fasta_writes_all_five_files_like_bwaidx(tmp_path):
+    """cs_index_build_fasta == bwa_idx_build (index_main.c:257-325): .bwt .sa .pac .ann .amb, md5-identical to the reference's bwaidx output"""
+    import hashlib
+    import json
+    import compseed_amd as ca
+    man = json.load(open(os.path.join(_data.HERE, "golden", "MANIFEST.json")))["md5"]
+    ca.build_index_from_fasta(os.path.join(_data.GOLD, "ref.fa.gz"), str(tmp_path / "idx"), 0)
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert hashlib.md5(open(tmp_path / ("idx." + ext), "rb").read()).hexdigest() == man["g1/ref." + ext], ext
