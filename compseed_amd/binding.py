@@ -11,7 +11,7 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 
 # every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
-           "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta",
+           "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta", "cs_reader_open", "cs_reader_next", "cs_reader_close",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
@@ -180,6 +180,10 @@ def load_library():
     L.cs_refseq_free.argtypes = [vp]
     L.cs_refseq_free.restype = None
     L.cs_index_build_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.cs_reader_open.argtypes = [C.c_char_p, C.c_int64, C.POINTER(vp)]
+    L.cs_reader_next.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.cs_reader_close.argtypes = [vp]
+    L.cs_reader_close.restype = None
     L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
     L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
     L.cs_engine_destroy.argtypes = [vp]
@@ -305,6 +309,37 @@ class RefSeq:
     def close(self):
         if self._h:
             load_library().cs_refseq_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Reader:
+    """chunks of a reordered-reads or FASTQ file (plain or gzip) as the engine takes them (cs_reader_t); iterate for (bases, offsets)
+    views of the reader's two alternating buffers: a chunk is valid until the one after the next is read"""
+
+    def __init__(self, path, chunk_bases=10_000_000):
+        self._h = C.c_void_p()
+        _check(load_library().cs_reader_open(os.fsencode(path), int(chunk_bases), C.byref(self._h)))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b, o, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _check(load_library().cs_reader_next(self._h, C.byref(b), C.byref(o), C.byref(n)))
+        if n.value == 0:
+            raise StopIteration
+        off = _view(o.value, "<u8", n.value + 1, False)
+        return _view(b.value, np.uint8, int(off[-1]), False), off
+
+    def close(self):
+        if self._h:
+            load_library().cs_reader_close(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

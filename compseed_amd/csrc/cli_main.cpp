@@ -15,32 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
-struct Chunk { std::vector<uint8_t> bases; std::vector<uint64_t> off; };
-
-static bool read_chunk(FILE *fp, bool fastq, long chunk_bases, Chunk &c)
-{
-	c.bases.clear(); c.off.assign(1, 0);
-	static std::vector<char> line(1 << 17);
-	long size = 0;
-	for (;;) {
-		if (!fgets(line.data(), (int)line.size(), fp)) break;
-		if (fastq) { // 4-line records: @name / sequence / + / quality
-			if (line[0] != '@') break;
-			if (!fgets(line.data(), (int)line.size(), fp)) break;
-		}
-		size_t l = strlen(line.data());
-		while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) --l;
-		c.bases.insert(c.bases.end(), line.begin(), line.begin() + l);
-		c.off.push_back(c.bases.size());
-		size += (long)l;
-		if (fastq) { char tmp[1 << 16]; if (!fgets(tmp, sizeof tmp, fp) || !fgets(tmp, sizeof tmp, fp)) break; }
-		if (size >= chunk_bases && ((c.off.size() - 1) & 1) == 0) break; // main.cpp:54
-	}
-	return c.off.size() > 1;
-}
+// a chunk as the reader delivers it, and its per-GPU read ranges with offsets rebased to 0 (they must live until the chunk is collected)
+struct Chunk { const uint8_t *bases = nullptr; const uint64_t *off = nullptr; int64_t n = 0; uint64_t first_id = 0; std::vector<std::vector<uint64_t>> loff; };
 
 static void usage()
 {
@@ -103,56 +81,68 @@ int main(int argc, char **argv)
 	for (int g = 0; g < n_gpus; ++g)
 		if (cs_engine_create_opts(&view, g, &eopt, &eng[g])) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); return 1; }
 
-	FILE *fp = fopen(pos[1], "r");
-	if (!fp) { fprintf(stderr, "[E::main] fail to open file `%s'.\n", pos[1]); return 1; }
-	int first = fgetc(fp); ungetc(first, fp);
-	bool fastq = first == '@';
 	FILE *fo = dump ? fopen(dump, "w") : nullptr;
 	if (dump && !fo) { fprintf(stderr, "[E::main] cannot write %s\n", dump); return 1; }
 	long chunk_bases = fixed_chunk > 0 ? fixed_chunk : 10000000L * n_threads; // main.cpp:437
+	cs_reader_t *rd = nullptr;
+	if (cs_reader_open(pos[1], chunk_bases, &rd)) { fprintf(stderr, "[E::main] %s\n", cs_last_error()); return 1; }
 
-	Chunk c; uint64_t n_processed = 0;
-	while (read_chunk(fp, fastq, chunk_bases, c)) {
-		int64_t n = (int64_t)c.off.size() - 1;
-		for (int64_t r = 0; r < n; ++r)
-			if (c.off[r + 1] - c.off[r] >= 65535) { // MAX_READ_LEN, main.cpp:83-86 (the reference aborts here)
-				fprintf(stderr, "[E::process] Read length of %ld exceeds the limit %d\n", (long)(c.off[r + 1] - c.off[r]), 65535);
-				return 1;
-			}
-		// contiguous read ranges per GPU keep neighbouring (overlapping) reads together
-		std::vector<cs_result_t> res((size_t)n_gpus);
-		std::vector<int> rc((size_t)n_gpus, 0);
-		std::vector<std::string> err((size_t)n_gpus);
-		std::vector<std::vector<uint64_t>> loff((size_t)n_gpus);
-		std::vector<std::thread> th;
+	// The reference's three-step pipeline (main.cpp:438) with the GPUs in the middle: chunk n+1 is read and submitted while chunk n
+	// is being seeded; every GPU gets a contiguous read range of each chunk (neighbouring, overlapping reads stay together).
+	auto read_chunk = [&](Chunk &c, uint64_t first_id) -> bool {
+		if (cs_reader_next(rd, &c.bases, &c.off, &c.n)) { fprintf(stderr, "[E::process] %s\n", cs_last_error()); exit(1); }
+		c.first_id = first_id;
+		return c.n > 0;
+	};
+	auto submit = [&](Chunk &c) {
+		c.loff.assign((size_t)n_gpus, std::vector<uint64_t>());
 		for (int g = 0; g < n_gpus; ++g) {
-			int64_t r0 = n * g / n_gpus, r1 = n * (g + 1) / n_gpus;
-			loff[g].resize((size_t)(r1 - r0) + 1);
-			for (int64_t r = r0; r <= r1; ++r) loff[g][(size_t)(r - r0)] = c.off[r] - c.off[r0];
-			th.emplace_back([&, g, r0, r1]() {
-				rc[g] = cs_engine_seed_batch(eng[g], &par, r1 - r0, c.bases.data() + c.off[r0], loff[g].data(), &res[g]);
-				if (rc[g]) err[g] = cs_last_error();
-			});
+			const int64_t r0 = c.n * g / n_gpus, r1 = c.n * (g + 1) / n_gpus;
+			c.loff[g].resize((size_t)(r1 - r0) + 1);
+			for (int64_t r = r0; r <= r1; ++r) c.loff[g][(size_t)(r - r0)] = c.off[r] - c.off[r0];
+			if (cs_engine_submit(eng[g], &par, r1 - r0, c.bases + c.off[r0], c.loff[g].data())) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); exit(1); }
 		}
-		for (auto &t : th) t.join();
-		for (int g = 0; g < n_gpus; ++g) if (rc[g]) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, err[g].c_str()); return 1; }
-		if (fo)
-			for (int g = 0; g < n_gpus; ++g) {
-				int64_t r0 = n * g / n_gpus;
-				const cs_result_t &R = res[g];
-				for (int64_t r = 0; r < R.n_reads; ++r) {
-					uint64_t id = n_processed + (uint64_t)(r0 + r) + 1; // read names are running integers from 1 (main.cpp:47)
-					for (uint64_t m = R.mem_off[r]; m < R.mem_off[r + 1]; ++m)
-						fprintf(fo, "M\t%lu\t%u\t%u\t%lu\t%lu\t%lu\n", (unsigned long)id, (unsigned)(R.mems[m].info >> 32), (unsigned)R.mems[m].info,
-						        (unsigned long)R.mems[m].x0, (unsigned long)R.mems[m].x1, (unsigned long)R.mems[m].x2);
-					if (R.seed_off)
-						for (uint64_t s = R.seed_off[r]; s < R.seed_off[r + 1]; ++s)
-							fprintf(fo, "S\t%lu\t%d\t%d\t%ld\n", (unsigned long)id, R.seeds[s].qbeg, R.seeds[s].len, (long)R.seeds[s].rbeg);
+	};
+	auto collect = [&](Chunk &c) {
+		for (int g = 0; g < n_gpus; ++g) {
+			cs_packed_result_t R;
+			if (cs_engine_collect_packed(eng[g], &R)) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); exit(1); }
+			if (!fo) continue;
+			const int64_t r0 = c.n * g / n_gpus;
+			for (int64_t r = 0; r < R.n_reads; ++r) {
+				const uint64_t id = c.first_id + (uint64_t)(r0 + r) + 1; // read names are running integers from 1 (main.cpp:47)
+				uint64_t sd = R.seed_off ? R.seed_off[r] : 0;
+				for (uint64_t m = R.mem_off[r]; m < R.mem_off[r + 1]; ++m) {
+					cs_intv_t v; cs_unpack_mem(&R, m, &v);
+					fprintf(fo, "M\t%lu\t%u\t%u\t%lu\t%lu\t%lu\n", (unsigned long)id, (unsigned)(v.info >> 32), (unsigned)v.info, (unsigned long)v.x0, (unsigned long)v.x1, (unsigned long)v.x2);
 				}
+				if (R.seed_off)
+					for (uint64_t m = R.mem_off[r]; m < R.mem_off[r + 1]; ++m) {
+						cs_intv_t v; cs_unpack_mem(&R, m, &v);
+						const uint32_t cnt = cs_mem_seed_count(&v, R.max_occ);
+						for (uint32_t k = 0; k < cnt; ++k)
+							fprintf(fo, "S\t%lu\t%d\t%d\t%ld\n", (unsigned long)id, (int)(v.info >> 32), (int)((uint32_t)v.info - (uint32_t)(v.info >> 32)), (long)R.seed_rbeg[sd + k]);
+						sd += cnt;
+					}
 			}
-		n_processed += (uint64_t)n;
+		}
+	};
+	Chunk ch[2];
+	uint64_t n_processed = 0;
+	int cur = 0;
+	if (read_chunk(ch[0], 0)) {
+		submit(ch[0]);
+		for (;;) {
+			Chunk &c = ch[cur], &nx = ch[cur ^ 1];
+			const bool more = read_chunk(nx, n_processed + (uint64_t)c.n);
+			if (more) submit(nx);
+			collect(c);
+			n_processed += (uint64_t)c.n;
+			if (!more) break;
+			cur ^= 1;
+		}
 	}
-	fclose(fp);
+	cs_reader_close(rd);
 	if (fo) fclose(fo);
 
 	cs_stats_t tot; memset(&tot, 0, sizeof tot);

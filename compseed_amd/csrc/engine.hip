@@ -1261,6 +1261,8 @@ static void pipe_seed_thread(cs_engine *e)
 			if (k >= 2) hipf(hipEventSynchronize(e->hp_ev_dn[(k - 2) % 4]), "waiting for a download");
 			// the batch that used this pinned result slot before may still be in the caller's hands: wait until it is given back
 			{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || hp.handed < 0 || (uint64_t)hp.handed == j.batch || ((uint64_t)hp.handed & 1) != (j.batch & 1); }); if (hp.quit) return; }
+			// (from here on the result slot is this batch's) offsets: one entry per read + 1
+			if (j.part == 0 && (e->hp_moff[rs].reserve((size_t)j.n_reads + 1) != CS_OK || (sal && e->hp_soff[rs].reserve((size_t)j.n_reads + 1) != CS_OK))) { rc = CS_ENOMEM; err = g_err; }
 			// pinned room for the whole batch: estimated from its first part, grown (keeping what has arrived) if that was too little
 			const size_t need_m = (size_t)(mem_base + nm), need_s = (size_t)(seed_base + ns);
 			if (need_m * msz > e->hp_mems[rs].cap || (sal && need_s > e->hp_rbeg[rs].cap)) {
@@ -1357,10 +1359,7 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	{ // buffers the threads will use: sized here, while no part of this batch is in flight (earlier batches never need more than they have)
 		std::unique_lock<std::mutex> lk(hp.mu);
 		const bool idle = hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1];
-		if (in_cap + 64 > e->hp_in[0].cap || off_cap > e->hp_inoff[0].cap || off_cap > e->hp_pk_moff[0].cap || (par->want_sal && off_cap > e->hp_pk_soff[0].cap) ||
-		    (size_t)n_reads + 1 > e->hp_moff[rs].cap || (par->want_sal && (size_t)n_reads + 1 > e->hp_soff[rs].cap)) {
-			if (hp.handed >= 0 && ((uint64_t)hp.handed & 1) == (uint64_t)rs && ((size_t)n_reads + 1 > e->hp_moff[rs].cap || (par->want_sal && (size_t)n_reads + 1 > e->hp_soff[rs].cap)))
-				return fail(CS_EINVAL, "cs_engine_submit: this batch is larger than any before and its result slot is still in the caller's hands; collect first");
+		if (in_cap + 64 > e->hp_in[0].cap || off_cap > e->hp_inoff[0].cap || off_cap > e->hp_pk_moff[0].cap || (par->want_sal && off_cap > e->hp_pk_soff[0].cap)) {
 			if (!idle) hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[rs ^ 1].parts_queued == hp.bs[rs ^ 1].parts_total); });
 			lk.unlock();
 			HIP_TRY(hipStreamSynchronize(e->s_down));
@@ -1368,14 +1367,11 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 				CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
 				if (par->want_sal) CS_TRY(e->hp_pk_soff[k].reserve(off_cap));
 			}
-			CS_TRY(e->hp_moff[rs].reserve((size_t)n_reads + 1));
-			if (par->want_sal) CS_TRY(e->hp_soff[rs].reserve((size_t)n_reads + 1));
 			lk.lock();
 		}
 		BatchState &b = hp.bs[rs];
 		b = BatchState();
 		b.id = id; b.n_reads = n_reads; b.parts_total = (int)kparts; b.pk16 = parts[0].pk16; b.sal = par->want_sal != 0; b.expand = expand; b.max_occ = par->max_occ;
-		e->hp_moff[rs].p[0] = 0; if (b.sal) e->hp_soff[rs].p[0] = 0;
 		for (auto &j : parts) hp.q_up.push_back(j);
 		hp.n_submitted++;
 		e->last.valid = false;

@@ -242,6 +242,16 @@ static inline uint32_t cs_mem_seed_count(const cs_intv_t *m, int32_t max_occ) { 
 int  cs_host_alloc(size_t bytes, void **ptr);
 int  cs_host_free(void *ptr);
 
+/* ---- reordered-reads ingest: the reader step of the reference's pipeline (input_reorder_reads, main.cpp:36-58; FASTQ when the first
+ *      byte is '@', main.cpp:399-406; plain or gzip), cutting chunks as main.cpp:54,437 does (the first even read count that reaches
+ *      chunk_bases) and delivering them as the engine takes them: bases back to back in pinned memory + n_reads + 1 offsets.  Two
+ *      chunk buffers alternate, so a chunk stays intact while the next one is read (submit chunk n+1, collect chunk n, read chunk n+2).
+ *      n_reads == 0: end of input. */
+typedef struct cs_reader cs_reader_t;
+int  cs_reader_open(const char *path, int64_t chunk_bases, cs_reader_t **out);
+int  cs_reader_next(cs_reader_t *r, const uint8_t **bases, const uint64_t **offsets, int64_t *n_reads);
+void cs_reader_close(cs_reader_t *r);
+
 /* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array
  *      (sum over the array's 64-bit words w[i] of splitmix64(w[i] + i * 0x9E3779B97F4A7C15), mod 2^64), so that two runs over
  *      10 M reads can be compared word for word without downloading 6 GB; and the CSR slice of selected reads (any order,

@@ -229,6 +229,8 @@ def test_full_baseline_size_properties():
     G = synth.make_genome(3_100_000_000, seed=20261003, device="cuda")
     ix = ca.Index.build(G.cpu().numpy(), 0)
     bases, off = synth.make_reads(G, n, 150, seed=777, p_sub=0.005, sort=True)
+    # two more chunks of the same run for the streamed part at the end (BASELINE configs[2])
+    extra = [synth.make_reads(G, n, 150, seed=778 + j, p_sub=0.005, sort=True, lo_frac=0.3 * (j + 1), hi_frac=0.3 * (j + 1) + 0.3)[0] for j in range(2)]
     del G
     torch.cuda.empty_cache()
     assert ix.view.seq_len + 1 > 2**32
@@ -271,4 +273,37 @@ def test_full_baseline_size_properties():
         assert st0["reseed_text_calls"] == 0 and st0["r3_text_seeds"] == 0 and st0["bwt_calls"] == st0["bwt_queries"]
         assert eng.result_digest() == d_on, kw                                     # all 10 M reads, all four arrays
         eng.reset_stats()
+    # ---- BASELINE configs[2] shape: ~600 M reads streamed through ONE GPU as 60 chunks of 10 M, two chunks in flight (cs_engine_submit /
+    # cs_engine_collect_packed), the chunks coming from pinned host buffers as a reader would deliver them.  Three distinct chunks are cycled
+    # (generating 90 GB of distinct text would only time the generator); every collected chunk must be exactly the result the device
+    # variant gives for that chunk: counts, offsets, and the packed mems / seeds of a strided sample.
+    ho = off.cpu().numpy().astype(np.uint64)
+    chunks = []
+    for t in [bases] + extra:
+        pin = ca.pinned_array(t.numel()); pin[:] = t.cpu().numpy()
+        r = eng.seed_batch_device(t.data_ptr(), off.data_ptr(), n, t.numel())
+        mo = eng.download(r.ptr["mem_off"], np.uint64, n + 1)
+        g = eng.gather_reads(ids)
+        chunks.append(dict(pin=pin, n_mems=r.n_mems, n_seeds=r.n_seeds, mo_sum=int(mo.sum(dtype=np.uint64)), mems=g.mems.copy(), rbeg=g.seeds["rbeg"].copy(), mem_off=mo))
+    del extra
+    assert len({c["n_mems"] for c in chunks}) == 3                                # the three chunks really differ
+    import time
+    n_chunks, done = 60, 0
+    eng.submit(chunks[0]["pin"], ho); eng.submit(chunks[1]["pin"], ho)
+    t0 = time.perf_counter()
+    for i in range(n_chunks):
+        p = eng.collect_packed()
+        c = chunks[i % 3]
+        assert (p["n_reads"], p["n_mems"], p["n_seeds"]) == (n, c["n_mems"], c["n_seeds"]), i
+        if i % 7 == 0:                                                             # full offsets + a strided sample of mems and seeds
+            assert int(p["mem_off"].sum(dtype=np.uint64)) == c["mo_sum"]
+            sel_m = np.concatenate([np.arange(int(p["mem_off"][r]), int(p["mem_off"][r + 1])) for r in ids.astype(np.int64)])
+            sel_s = np.concatenate([np.arange(int(p["seed_off"][r]), int(p["seed_off"][r + 1])) for r in ids.astype(np.int64)])
+            assert np.array_equal(ca.unpack_mems16(p["mems"][sel_m]), c["mems"]) and np.array_equal(p["seed_rbeg"][sel_s], c["rbeg"]), i
+        if i + 2 < n_chunks:
+            eng.submit(chunks[(i + 2) % 3]["pin"], ho)
+        done += n
+    dt = time.perf_counter() - t0
+    print("streamed %d reads in %.2f s: %.1f M reads/s incl. PCIe" % (done, dt, done / dt / 1e6))
+    assert done == 600_000_000
     o.close(); eng.close(); ix.close()
