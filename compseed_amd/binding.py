@@ -12,6 +12,7 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 # every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
            "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta", "cs_reader_open", "cs_reader_next", "cs_reader_close",
+           "cs_chainer_create", "cs_chainer_destroy", "cs_chain_params_default", "cs_chain_batch",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
@@ -71,6 +72,21 @@ class EngineOptions(C.Structure):
 class CResult(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_mems", C.c_uint64), ("n_seeds", C.c_uint64), ("mem_off", C.c_void_p),
                 ("mems", C.c_void_p), ("seed_off", C.c_void_p), ("seeds", C.c_void_p)]
+
+
+class ChainParams(C.Structure):
+    _fields_ = [("w", C.c_int32), ("max_chain_gap", C.c_int32), ("min_seed_len", C.c_int32), ("max_occ", C.c_int32)]
+
+    def __init__(self, w=100, max_chain_gap=10000, k=19, c=500):
+        super().__init__(w, max_chain_gap, k, c)
+
+
+class CChainResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_chains", C.c_uint64), ("n_seeds", C.c_uint64), ("chain_off", C.c_void_p), ("chains", C.c_void_p),
+                ("cseed_off", C.c_void_p), ("cseeds", C.c_void_p)]
+
+
+CHAIN_DT = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n_seeds", "<i4"), ("frac_rep", "<f4"), ("is_alt", "<i4")])   # cs_chain_t
 
 
 class CPacked(C.Structure):
@@ -184,6 +200,12 @@ def load_library():
     L.cs_reader_next.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
     L.cs_reader_close.argtypes = [vp]
     L.cs_reader_close.restype = None
+    L.cs_chainer_create.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.cs_chainer_destroy.argtypes = [vp]
+    L.cs_chainer_destroy.restype = None
+    L.cs_chain_params_default.argtypes = [C.POINTER(ChainParams)]
+    L.cs_chain_params_default.restype = None
+    L.cs_chain_batch.argtypes = [vp, C.POINTER(ChainParams), C.POINTER(CResult), vp, C.c_int, C.POINTER(CChainResult)]
     L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
     L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
     L.cs_engine_destroy.argtypes = [vp]
@@ -340,6 +362,37 @@ class Reader:
     def close(self):
         if self._h:
             load_library().cs_reader_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Chainer:
+    """mem_chain over a batch's seeds (cs_chainer_t); needs <prefix>.ann"""
+
+    def __init__(self, prefix):
+        self._h = C.c_void_p()
+        _check(load_library().cs_chainer_create(os.fsencode(prefix), C.byref(self._h)))
+
+    def chain(self, mem_off, mems, seed_off, seeds, read_offsets, params=None, threads=4):
+        """host CSR seeds (numpy arrays as Result holds them) -> dict(chain_off, chains (CHAIN_DT), cseed_off, cseeds (SEED_DT)), copies"""
+        params = params or ChainParams()
+        mem_off = np.ascontiguousarray(mem_off, dtype=np.uint64); seed_off = np.ascontiguousarray(seed_off, dtype=np.uint64)
+        mems = np.ascontiguousarray(mems, dtype=INTV_DT); seeds = np.ascontiguousarray(seeds, dtype=SEED_DT)
+        ro = np.ascontiguousarray(read_offsets, dtype=np.uint64)
+        res = CResult(mem_off.size - 1, mems.size, seeds.size, mem_off.ctypes.data, mems.ctypes.data, seed_off.ctypes.data, seeds.ctypes.data)
+        out = CChainResult()
+        _check(load_library().cs_chain_batch(self._h, C.byref(params), C.byref(res), ro.ctypes.data, int(threads), C.byref(out)))
+        return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1), chains=_view(out.chains, CHAIN_DT, int(out.n_chains)),
+                    cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds)))
+
+    def close(self):
+        if self._h:
+            load_library().cs_chainer_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

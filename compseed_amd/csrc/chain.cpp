@@ -1,0 +1,242 @@
+// chain.cpp -- seed -> chain hand-off: the first consumer of the engine's output, mem_chain of the reference
+// (mapping/comp_seed.cpp:241-285 with test_and_merge :182-203, bns_intv2rid FM_index/bntseq.c:370-378, frac_rep :271-280), as host
+// code over the CSR result of a whole batch.  It proves the seeds are usable by the next stage: the chains are the reference's, chain
+// by chain and seed by seed (tests/test_chain.py: golden chains dumped from the reference's own mem_chain on 14 runs).
+//
+// What has to be reproduced besides the merge rule is the ORDER and the CHOICE of chains.  The reference keeps a read's chains in a
+// B-tree keyed by the chain's first reference position (cstl/kbtree.h, at most 9 keys per node for this key type) and asks it for the
+// chain with the largest key <= the seed's position.  Keys are not unique (tandem repeats give chains with equal positions), and which
+// of several equal keys the search returns, and where a new equal key lands, depends on how the tree has split so far; the final
+// traversal is in tree order.  So the tree is restated here with the same search and insertion rules (lower bound inside a node, the
+// first equal key on the way down wins, a new key goes right behind the position the search ends at, full children are split before
+// descending, the median moves up) over (position, chain id) pairs.
+#include "cs_internal.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct cs_refseq_view { int64_t l_pac; std::vector<int64_t> offset; std::vector<int32_t> len; };
+
+struct cs_chainer { cs_refseq_view ref; std::vector<cs_chain_t> chains; std::vector<uint64_t> chain_off, cseed_off; std::vector<cs_seed_t> cseeds; };
+
+namespace {
+constexpr int BT = 5, BMAX = 2 * BT - 1; // kb_init(chn, 512) with a 40-byte key: t = ((512 - 4 - 8) / (8 + 40) + 1) >> 1 = 5 (cstl/kbtree.h:57-62)
+
+struct Node { int n; bool internal; int64_t pos[BMAX]; int32_t id[BMAX]; int32_t kid[BMAX + 1]; };
+
+struct Tree { // node 0 is the root until it splits; nodes live in a vector that is reused from read to read
+	std::vector<Node> nd; int root = 0; int size = 0;
+	void clear() { nd.clear(); Node r; memset(&r, 0, sizeof r); nd.push_back(r); root = 0; size = 0; }
+	// index of the last key <= k inside node x, the FIRST one among equal keys (r = 0 then); -1 if all keys are larger
+	static int locate(const Node &x, int64_t k, int &r)
+	{
+		int begin = 0, end = x.n;
+		if (x.n == 0) { r = 1; return -1; }
+		while (begin < end) { int mid = (begin + end) >> 1; if (x.pos[mid] < k) begin = mid + 1; else end = mid; }
+		if (begin == x.n) { r = 1; return x.n - 1; }
+		r = k < x.pos[begin] ? -1 : 0;
+		return r < 0 ? begin - 1 : begin;
+	}
+	int lower(int64_t k) const // chain id of the closest key <= k as kb_intervalp reports it, or -1
+	{
+		int lo = -1, x = root;
+		for (;;) {
+			int r, i = locate(nd[x], k, r);
+			if (i >= 0 && r == 0) return nd[x].id[i];
+			if (i >= 0) lo = nd[x].id[i];
+			if (!nd[x].internal) return lo;
+			x = nd[x].kid[i + 1];
+		}
+	}
+	void split(int x, int i, int y) // y = full child i of x: its upper half becomes a new node, its median moves up into x
+	{
+		Node z; memset(&z, 0, sizeof z);
+		z.internal = nd[y].internal; z.n = BT - 1;
+		memcpy(z.pos, nd[y].pos + BT, sizeof(int64_t) * (BT - 1)); memcpy(z.id, nd[y].id + BT, sizeof(int32_t) * (BT - 1));
+		if (nd[y].internal) memcpy(z.kid, nd[y].kid + BT, sizeof(int32_t) * BT);
+		nd[y].n = BT - 1;
+		const int zi = (int)nd.size();
+		nd.push_back(z);
+		Node &X = nd[x];
+		memmove(X.kid + i + 2, X.kid + i + 1, sizeof(int32_t) * (X.n - i));
+		X.kid[i + 1] = zi;
+		memmove(X.pos + i + 1, X.pos + i, sizeof(int64_t) * (X.n - i)); memmove(X.id + i + 1, X.id + i, sizeof(int32_t) * (X.n - i));
+		X.pos[i] = nd[y].pos[BT - 1]; X.id[i] = nd[y].id[BT - 1];
+		++X.n;
+	}
+	void put(int64_t k, int32_t id)
+	{
+		++size;
+		if (nd[root].n == BMAX) {
+			Node s; memset(&s, 0, sizeof s); s.internal = true; s.kid[0] = root;
+			const int si = (int)nd.size(); nd.push_back(s);
+			split(si, 0, root);
+			root = si;
+		}
+		int x = root;
+		for (;;) {
+			int r, i = locate(nd[x], k, r);
+			if (!nd[x].internal) {
+				Node &X = nd[x];
+				if (i != X.n - 1) { memmove(X.pos + i + 2, X.pos + i + 1, sizeof(int64_t) * (X.n - i - 1)); memmove(X.id + i + 2, X.id + i + 1, sizeof(int32_t) * (X.n - i - 1)); }
+				X.pos[i + 1] = k; X.id[i + 1] = id; ++X.n;
+				return;
+			}
+			++i;
+			if (nd[nd[x].kid[i]].n == BMAX) {
+				split(x, i, nd[x].kid[i]);
+				if (k > nd[x].pos[i]) ++i;
+			}
+			x = nd[x].kid[i];
+		}
+	}
+	template <class F> void traverse(int x, F &f) const
+	{
+		const Node &X = nd[x];
+		for (int i = 0; i <= X.n; ++i) {
+			if (X.internal) traverse(X.kid[i], f);
+			if (i < X.n) f(X.id[i]);
+		}
+	}
+};
+
+struct Chain { int64_t pos; int32_t rid; std::vector<cs_seed_t> seeds; };
+
+inline int pos2rid(const cs_refseq_view &R, int64_t pos_f) // bns_pos2rid, bntseq.c:346-362
+{
+	if (pos_f >= R.l_pac) return -1;
+	const int n = (int)R.offset.size();
+	int left = 0, mid = 0, right = n;
+	while (left < right) {
+		mid = (left + right) >> 1;
+		if (pos_f >= R.offset[mid]) {
+			if (mid == n - 1) break;
+			if (pos_f < R.offset[mid + 1]) break;
+			left = mid + 1;
+		} else right = mid;
+	}
+	return mid;
+}
+inline int64_t depos(const cs_refseq_view &R, int64_t pos) { return pos >= R.l_pac ? (R.l_pac << 1) - 1 - pos : pos; } // bns_depos, bntseq.h:87
+inline int intv2rid(const cs_refseq_view &R, int64_t rb, int64_t re) // bns_intv2rid, bntseq.c:370-378
+{
+	if (rb < R.l_pac && re > R.l_pac) return -2;
+	const int rid_b = pos2rid(R, depos(R, rb));
+	const int rid_e = rb < re ? pos2rid(R, depos(R, re - 1)) : rid_b;
+	return rid_b == rid_e ? rid_b : -1;
+}
+// test_and_merge, comp_seed.cpp:182-203: 1 if the seed is contained in or appended to the chain
+inline bool test_and_merge(const cs_chain_params_t &opt, int64_t l_pac, Chain &c, const cs_seed_t &p, int seed_rid)
+{
+	const cs_seed_t &last = c.seeds.back(), &first = c.seeds.front();
+	const int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
+	if (seed_rid != c.rid) return false;
+	if (p.qbeg >= first.qbeg && p.qbeg + p.len <= qend && p.rbeg >= first.rbeg && p.rbeg + p.len <= rend) return true;
+	if ((last.rbeg < l_pac || first.rbeg < l_pac) && p.rbeg >= l_pac) return false;
+	const int64_t x = p.qbeg - last.qbeg, y = p.rbeg - last.rbeg;
+	if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - last.len < opt.max_chain_gap && y - last.len < opt.max_chain_gap) { c.seeds.push_back(p); return true; }
+	return false;
+}
+
+struct ReadOut { std::vector<cs_chain_t> chains; std::vector<cs_seed_t> seeds; std::vector<uint32_t> per_read; };
+
+void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs_result_t &S, const uint64_t *read_off, int64_t r0, int64_t r1, ReadOut &out)
+{
+	Tree tree; std::vector<Chain> pool;
+	for (int64_t r = r0; r < r1; ++r) {
+		const int len = (int)(read_off[r + 1] - read_off[r]);
+		uint32_t n_out = 0;
+		if (len >= opt.min_seed_len) {
+			tree.clear(); pool.clear();
+			for (uint64_t si = S.seed_off[r]; si < S.seed_off[r + 1]; ++si) {
+				const cs_seed_t &s = S.seeds[si];
+				const int rid = intv2rid(R, s.rbeg, s.rbeg + s.len);
+				if (rid < 0) continue; // bridging two sequences or the forward-reverse boundary (comp_seed.cpp:251)
+				bool add = true;
+				if (tree.size) { const int lo = tree.lower(s.rbeg); if (lo >= 0 && test_and_merge(opt, R.l_pac, pool[lo], s, rid)) add = false; }
+				if (add) { Chain c; c.pos = s.rbeg; c.rid = rid; c.seeds.push_back(s); pool.push_back(std::move(c)); tree.put(s.rbeg, (int32_t)pool.size() - 1); }
+			}
+			// fraction of the read covered by repetitive mems (comp_seed.cpp:271-280); the mems are sorted by interval
+			int beg = 0, end = 0, l_rep = 0;
+			for (uint64_t m = S.mem_off[r]; m < S.mem_off[r + 1]; ++m) {
+				if (S.mems[m].x2 <= (uint64_t)opt.max_occ) continue;
+				const int b = (int)(S.mems[m].info >> 32), e = (int)(uint32_t)S.mems[m].info;
+				if (b > end) { l_rep += end - beg; beg = b; end = e; } else end = std::max(end, e);
+			}
+			l_rep += end - beg;
+			const float frac = (float)l_rep / len;
+			auto emit = [&](int32_t id) {
+				const Chain &c = pool[id];
+				cs_chain_t o; o.pos = c.pos; o.rid = c.rid; o.n_seeds = (int32_t)c.seeds.size(); o.frac_rep = frac; o.is_alt = 0;
+				out.chains.push_back(o); out.seeds.insert(out.seeds.end(), c.seeds.begin(), c.seeds.end());
+				++n_out;
+			};
+			if (tree.size) tree.traverse(tree.root, emit);
+		}
+		out.per_read.push_back(n_out);
+	}
+}
+} // namespace
+
+// contig table from <prefix>.ann (bns_restore_core, bntseq.c:97-140: "l_pac n_seqs seed", then per sequence "gi name [comment]" and "offset len n_ambs")
+extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
+{
+	if (!prefix || !out) return cs_fail_(CS_EINVAL, "cs_chainer_create: null argument");
+	*out = nullptr;
+	FILE *fp = fopen((std::string(prefix) + ".ann").c_str(), "r");
+	if (!fp) return cs_fail_(CS_EIO, std::string("cannot read ") + prefix + ".ann");
+	cs_chainer *c = new cs_chainer();
+	long long l_pac = 0; int n_seqs = 0; unsigned seed = 0;
+	bool ok = fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) == 3 && n_seqs > 0;
+	c->ref.l_pac = l_pac;
+	std::vector<char> line(1 << 16);
+	if (ok) ok = fgets(line.data(), (int)line.size(), fp) != nullptr; // rest of the first line
+	for (int i = 0; ok && i < n_seqs; ++i) {
+		long long off = 0; int len = 0, n_ambs = 0;
+		ok = fgets(line.data(), (int)line.size(), fp) != nullptr;                       // "gi name [comment]"
+		ok = ok && fscanf(fp, "%lld%d%d", &off, &len, &n_ambs) == 3;
+		if (ok) { c->ref.offset.push_back(off); c->ref.len.push_back(len); ok = fgets(line.data(), (int)line.size(), fp) != nullptr || i == n_seqs - 1; }
+	}
+	fclose(fp);
+	if (!ok) { delete c; return cs_fail_(CS_EIO, std::string(prefix) + ".ann is malformed"); }
+	*out = c;
+	return CS_OK;
+}
+extern "C" void cs_chainer_destroy(cs_chainer_t *c) { delete c; }
+
+extern "C" void cs_chain_params_default(cs_chain_params_t *p)
+{
+	if (!p) return;
+	p->w = 100; p->max_chain_gap = 10000; p->min_seed_len = 19; p->max_occ = 500; // mem_opt_init, comp_seed.cpp:26-58
+}
+
+extern "C" int cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, const cs_result_t *seeds, const uint64_t *read_offsets, int n_threads,
+                              cs_chain_result_t *out)
+{
+	if (!c || !par || !seeds || !out || (seeds->n_reads > 0 && (!read_offsets || !seeds->mem_off || !seeds->seed_off))) return cs_fail_(CS_EINVAL, "cs_chain_batch: bad argument (seeds are needed: want_sal = 1)");
+	const int64_t n = seeds->n_reads;
+	int T = std::max(1, std::min(n_threads, 256));
+	if (n < 1024) T = 1;
+	std::vector<ReadOut> part((size_t)T);
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; ++t) {
+		const int64_t r0 = n * t / T, r1 = n * (t + 1) / T;
+		if (T == 1) chain_range(c->ref, *par, *seeds, read_offsets, r0, r1, part[0]);
+		else th.emplace_back(chain_range, std::cref(c->ref), std::cref(*par), std::cref(*seeds), read_offsets, r0, r1, std::ref(part[(size_t)t]));
+	}
+	for (auto &t : th) t.join();
+	c->chains.clear(); c->cseeds.clear(); c->chain_off.assign(1, 0); c->cseed_off.assign(1, 0);
+	for (auto &p : part) {
+		for (uint32_t k : p.per_read) c->chain_off.push_back(c->chain_off.back() + k);
+		for (const auto &ch : p.chains) c->cseed_off.push_back(c->cseed_off.back() + (uint64_t)ch.n_seeds);
+		c->chains.insert(c->chains.end(), p.chains.begin(), p.chains.end());
+		c->cseeds.insert(c->cseeds.end(), p.seeds.begin(), p.seeds.end());
+	}
+	out->n_reads = n; out->n_chains = c->chains.size(); out->n_seeds = c->cseeds.size();
+	out->chain_off = c->chain_off.data(); out->chains = c->chains.data(); out->cseed_off = c->cseed_off.data(); out->cseeds = c->cseeds.data();
+	return CS_OK;
+}

@@ -252,6 +252,27 @@ int  cs_reader_open(const char *path, int64_t chunk_bases, cs_reader_t **out);
 int  cs_reader_next(cs_reader_t *r, const uint8_t **bases, const uint64_t **offsets, int64_t *n_reads);
 void cs_reader_close(cs_reader_t *r);
 
+/* ---- seed -> chain hand-off: mem_chain of the reference (mapping/comp_seed.cpp:241-285) over the seeds of a whole batch, host code.
+ *      A chain is a run of co-linear seeds on one reference sequence (test_and_merge, comp_seed.cpp:182-203); chains come out per read in
+ *      the order the reference's B-tree traversal gives them, each with the fraction of the read covered by repetitive mems.  The contig
+ *      table comes from <prefix>.ann.  `seeds` is a host-side result with seeds (want_sal = 1); read_offsets are the batch's offsets.
+ *      The arrays of the result belong to the chainer and stay valid until its next call. */
+typedef struct { int32_t w, max_chain_gap, min_seed_len, max_occ; } cs_chain_params_t;   /* mem_opt_t: -w 100, max_chain_gap 10000, -k, -c */
+typedef struct { int64_t pos; int32_t rid, n_seeds; float frac_rep; int32_t is_alt; } cs_chain_t;
+typedef struct {
+	int64_t n_reads; uint64_t n_chains, n_seeds;
+	const uint64_t *chain_off;     /* n_reads + 1 */
+	const cs_chain_t *chains;
+	const uint64_t *cseed_off;     /* n_chains + 1 */
+	const cs_seed_t *cseeds;       /* the seeds of chain c: cseeds[cseed_off[c] .. cseed_off[c + 1]) */
+} cs_chain_result_t;
+typedef struct cs_chainer cs_chainer_t;
+int  cs_chainer_create(const char *prefix, cs_chainer_t **out);
+void cs_chainer_destroy(cs_chainer_t *c);
+void cs_chain_params_default(cs_chain_params_t *p);
+int  cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, const cs_result_t *seeds, const uint64_t *read_offsets, int n_threads,
+                    cs_chain_result_t *out);
+
 /* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array
  *      (sum over the array's 64-bit words w[i] of splitmix64(w[i] + i * 0x9E3779B97F4A7C15), mod 2^64), so that two runs over
  *      10 M reads can be compared word for word without downloading 6 GB; and the CSR slice of selected reads (any order,

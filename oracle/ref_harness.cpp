@@ -35,6 +35,10 @@ thread_aux_t tprof; // comp_seed.cpp:22 declares it extern
 int collect_mem_with_sst(const uint8_t *seq, int len, int pivot, int min_hits, thread_aux_t &aux);
 int tem_forward_sst(const mem_opt_t *opt, const uint8_t *seq, int len, int start, bwtintv_t *mem, thread_aux_t &aux);
 
+// mem_chain (mapping/comp_seed.cpp:241) has external linkage but its return type lives in the .cpp: same layout declared here
+typedef struct { size_t n, m; mem_chain_t *a; } mem_chain_v;
+mem_chain_v mem_chain(const mem_opt_t *opt, const bntseq_t *bns, int len, const std::vector<bwtintv_t> &mem, const std::vector<mem_seed_t> &seed);
+
 static bool by_info(const bwtintv_t &a, const bwtintv_t &b) { return a.info < b.info; }
 
 // mapping/bwamem.c:218-272 replayed with the public bwt.h entry points
@@ -174,7 +178,7 @@ int main(int argc, char **argv)
 	}
 	mem_opt_t *opt = mem_opt_init();
 	int batch = BATCH_SIZE;
-	const char *prim_fn = 0; long prim_n = 0; uint64_t prim_seed = 1;
+	const char *prim_fn = 0, *chain_fn = 0; long prim_n = 0; uint64_t prim_seed = 1;
 	for (int i = 4; i < argc; i++) {
 		std::string a = argv[i];
 		if (a == "-k") opt->min_seed_len = atoi(argv[++i]);
@@ -184,11 +188,12 @@ int main(int argc, char **argv)
 		else if (a == "-s") opt->split_width = atoi(argv[++i]);
 		else if (a == "-B") batch = atoi(argv[++i]);
 		else if (a == "--prim") { prim_fn = argv[++i]; prim_n = atol(argv[++i]); prim_seed = strtoull(argv[++i], 0, 10); }
+		else if (a == "--chains") chain_fn = argv[++i];
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
 	}
 	if (batch < 1 || batch > BATCH_SIZE) { fprintf(stderr, "batch must be in [1,%d]\n", BATCH_SIZE); return 1; }
 	bwa_verbose = 1;
-	bwaidx_t *idx = bwa_idx_load(argv[1], BWA_IDX_BWT);
+	bwaidx_t *idx = bwa_idx_load(argv[1], chain_fn ? (BWA_IDX_BWT | BWA_IDX_BNS) : BWA_IDX_BWT);
 	if (!idx) { fprintf(stderr, "cannot load index %s\n", argv[1]); return 1; }
 	const bwt_t *bwt = idx->bwt;
 
@@ -271,5 +276,39 @@ int main(int argc, char **argv)
 	fprintf(stderr, "[ref_dump] reads=%zu mems=%zu seeds=%zu bwt_queries=%ld bwt_calls=%lu sal_queries=%lu sal_calls=%lu diffAB=%lu\n",
 	        n, mems.size(), seeds.size(), aux.bwt_query_times, (unsigned long)bwt_calls, (unsigned long)sal_queries, (unsigned long)sal_calls, (unsigned long)n_diff);
 	if (prim_fn) dump_prims(bwt, prim_fn, prim_n, prim_seed, mems);
+	if (chain_fn) { // the reference's own mem_chain on every read's mems and seeds (comp_seed.cpp:2361): chains in its traversal order
+		// file: char magic[8]="CSCHAIN1"; u64 n_reads, n_chains, n_seeds; u64 chain_off[n_reads+1];
+		//       {i64 pos; i32 rid, n; f32 frac_rep; i32 is_alt} chains[]; {i64 rbeg; i32 qbeg, len} seeds[] (chain after chain)
+		struct chain_out_t { int64_t pos; int32_t rid, n; float frac_rep; int32_t is_alt; };
+		std::vector<uint64_t> chain_off(n + 1, 0);
+		std::vector<chain_out_t> chains; std::vector<seed_out_t> cseeds;
+		for (size_t r = 0; r < n; r++) {
+			std::vector<bwtintv_t> match(mems.begin() + mem_off[r], mems.begin() + mem_off[r + 1]);
+			std::vector<mem_seed_t> sd;
+			for (uint64_t i = seed_off[r]; i < seed_off[r + 1]; i++) {
+				mem_seed_t s; memset(&s, 0, sizeof s);
+				s.rbeg = seeds[i].rbeg; s.qbeg = seeds[i].qbeg; s.len = s.score = seeds[i].len;
+				sd.push_back(s);
+			}
+			mem_chain_v cv = mem_chain(opt, idx->bns, (int)reads[r].size(), match, sd);
+			for (size_t c = 0; c < cv.n; c++) {
+				chain_out_t o = {cv.a[c].pos, cv.a[c].rid, cv.a[c].n, cv.a[c].frac_rep, (int32_t)cv.a[c].is_alt};
+				chains.push_back(o);
+				for (int j = 0; j < cv.a[c].n; j++) { seed_out_t s = {cv.a[c].seeds[j].rbeg, cv.a[c].seeds[j].qbeg, cv.a[c].seeds[j].len}; cseeds.push_back(s); }
+				free(cv.a[c].seeds);
+			}
+			free(cv.a);
+			chain_off[r + 1] = chains.size();
+		}
+		FILE *fc = fopen(chain_fn, "wb");
+		if (!fc) { perror(chain_fn); return 1; }
+		uint64_t h3[3] = {n, chains.size(), cseeds.size()};
+		fwrite("CSCHAIN1", 1, 8, fc); fwrite(h3, 8, 3, fc);
+		fwrite(chain_off.data(), 8, n + 1, fc);
+		fwrite(chains.data(), sizeof(chain_out_t), chains.size(), fc);
+		fwrite(cseeds.data(), sizeof(seed_out_t), cseeds.size(), fc);
+		fclose(fc);
+		fprintf(stderr, "[ref_dump] chains=%zu chained seeds=%zu\n", chains.size(), cseeds.size());
+	}
 	return n_diff ? 2 : 0;
 }

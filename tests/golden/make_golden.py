@@ -10,6 +10,7 @@ What is produced (all data, no reference source text):
   g1/ref.{bwt,sa,pac,ann,amb}        index built by the reference's own `bwaidx` (index_main.c:257)
   g1/<reads>.txt                     read sets, one read per line (CompSeed's reordered-reads format, main.cpp:36-58)
   g1/<reads>.<params>.npz            per-read sorted mem lists + SAL seeds + reference counters (ref_harness.cpp)
+  g1/<reads>.<params>.chains.npz     the chains the reference's mem_chain (comp_seed.cpp:241) builds from those mems and seeds
   g1/prims.npz                       known-answer vectors for bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_sa
   MANIFEST.json                      md5 of every file + the harness stderr summary per run
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
@@ -108,6 +109,18 @@ def parse_gold(path):
     seed_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
     sd = np.frombuffer(raw, dtype=np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")]), count=n_seeds, offset=off)
     return dict(counters=hdr.copy(), mem_off=mem_off.copy(), mems=mems.copy(), seed_off=seed_off.copy(),
+                seed_rbeg=sd["rbeg"].copy(), seed_qbeg=sd["qbeg"].copy(), seed_len=sd["len"].copy())
+
+
+def parse_chains(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"CSCHAIN1"
+    n, n_chains, n_seeds = [int(x) for x in np.frombuffer(raw, dtype="<u8", count=3, offset=8)]
+    off = 32
+    chain_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
+    ch = np.frombuffer(raw, dtype=np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n", "<i4"), ("frac_rep", "<f4"), ("is_alt", "<i4")]), count=n_chains, offset=off); off += 24 * n_chains
+    sd = np.frombuffer(raw, dtype=np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")]), count=n_seeds, offset=off)
+    return dict(chain_off=chain_off.copy(), pos=ch["pos"].copy(), rid=ch["rid"].copy(), n=ch["n"].copy(), frac_rep=ch["frac_rep"].copy(), is_alt=ch["is_alt"].copy(),
                 seed_rbeg=sd["rbeg"].copy(), seed_qbeg=sd["qbeg"].copy(), seed_len=sd["len"].copy())
 
 
@@ -216,9 +229,9 @@ def main():
     for name, rd in sets.items():
         with open(os.path.join(d, name + ".txt"), "w") as f:
             f.write("".join(x + "\n" for x in rd))
-    tmp = os.path.join(d, "_tmp.bin"); ptmp = os.path.join(d, "_prim.bin")
+    tmp = os.path.join(d, "_tmp.bin"); ptmp = os.path.join(d, "_prim.bin"); ctmp = os.path.join(d, "_chain.bin")
     for i, (name, pname) in enumerate(runs):
-        cmd = [os.path.join(REFBIN, "ref_dump"), os.path.join(d, "ref"), os.path.join(d, name + ".txt"), tmp] + PARAM_SETS[pname]
+        cmd = [os.path.join(REFBIN, "ref_dump"), os.path.join(d, "ref"), os.path.join(d, name + ".txt"), tmp] + PARAM_SETS[pname] + ["--chains", ctmp]
         if i == 0:
             cmd += ["--prim", ptmp, "4000", "7"]
         r = run(cmd)
@@ -227,11 +240,12 @@ def main():
         gold = parse_gold(tmp)
         assert int(gold["counters"][7]) == 0, "reference paths A and B disagree"
         np.savez_compressed(os.path.join(d, "%s.%s.npz" % (name, pname)), params=np.array(PARAM_SETS[pname], dtype="U16"), **gold)
-        manifest["runs"]["%s.%s" % (name, pname)] = r.stderr.strip().splitlines()[-1]
+        np.savez_compressed(os.path.join(d, "%s.%s.chains.npz" % (name, pname)), **parse_chains(ctmp))   # the reference's mem_chain on these mems / seeds
+        manifest["runs"]["%s.%s" % (name, pname)] = " | ".join(r.stderr.strip().splitlines()[-2:])
         if i == 0:
             np.savez_compressed(os.path.join(d, "prims.npz"), **parse_prims(ptmp))
             os.remove(ptmp)
-    os.remove(tmp)
+    os.remove(tmp); os.remove(ctmp)
     for fn in sorted(os.listdir(d)):
         manifest["md5"]["g1/" + fn] = md5(os.path.join(d, fn))
     json.dump(manifest, open(os.path.join(HERE, "MANIFEST.json"), "w"), indent=1, sort_keys=True)

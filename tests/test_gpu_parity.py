@@ -503,3 +503,16 @@ def test_submit_collect_pipeline_across_batches():
     got = e.seed_batch(data[0][1], data[0][2])               # and the blocking calls work again afterwards
     _check_against_golden(got, data[0][0])
     e.close(); ix.close()
+
+
+@pytest.mark.parametrize("name,pname", [("main100", "default"), ("repeat100", "default"), ("ragged", "k14"), ("sorted150", "r1.0"), ("main100", "c50s20")])
+def test_engine_output_chains_like_the_reference(eng, name, pname):
+    """seed -> chain hand-off on the engine's own output: cs_engine_seed_batch -> cs_chain_batch == the reference's mem_chain (golden chains)"""
+    import compseed_amd as ca
+    from test_chain import check_chains, golden_chains
+    z, kw = _data.load_golden(name, pname)
+    bases, off = _data.load_reads(name)
+    r = eng.seed_batch(bases, off, ca.Params(**kw))
+    c = ca.Chainer(_data.PREFIX)
+    check_chains(c.chain(r.mem_off, r.mems, r.seed_off, r.seeds, off, ca.ChainParams(k=kw.get("k", 19), c=kw.get("c", 500)), threads=4), golden_chains(name, pname))
+    c.close()
