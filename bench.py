@@ -377,6 +377,27 @@ def main():
                                    "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cpus": len(os.sched_getaffinity(0)),
                                    "sample": "first %d reads of rank 0's batch, oracle/cs_oracle.c in CompSeed mode (SST per 512 reads), %d threads, %.1f s"
                                              % (ncpu, cores, dt)}
+            # the REAL reference where its binary travelled with the snapshot (oracle/_ref/ref_dump, compiled from /root/reference in the build
+            # container; --time = its own collect_mem_with_sst / tem_forward_sst / bwt_sa on T threads, 512-read batches as kt_for hands them out)
+            ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+            if os.path.exists(ref_bin) and (args.k, args.r, args.s) == (19, 1.5, 10):
+                td = tempfile.mkdtemp(prefix="cs_refcpu_", dir="/tmp")
+                try:
+                    ix.save(os.path.join(td, "idx"))
+                    with open(os.path.join(td, "reads.txt"), "wb") as f:
+                        rows = cb.reshape(ncpu, args.read_len)
+                        f.write(np.concatenate([rows, np.full((ncpu, 1), 10, np.uint8)], axis=1).tobytes())
+                    rr = subprocess.run([ref_bin, os.path.join(td, "idx"), os.path.join(td, "reads.txt"), "/dev/null", "--time", str(cores),
+                                         "-y", str(args.y), "-c", str(args.c)], capture_output=True, text=True, timeout=300)
+                    rj = json.loads(rr.stdout.strip().splitlines()[-1])
+                    out["cpu_baseline"].update({"port_value": out["cpu_baseline"]["value"], "value": rj["reads_per_s"], "kind": "reference",
+                                                "sample": "first %d reads of rank 0's batch; the reference's own seeding + SAL code (oracle/_ref/ref_dump --time: "
+                                                          "collect_mem_with_sst / tem_forward_sst / bwt_sa, SSTs per 512 reads), %d threads, %.1f s; port_value = "
+                                                          "oracle/cs_oracle.c on the same sample" % (ncpu, cores, rj["seconds"])})
+                except Exception as ex:  # noqa: BLE001
+                    log("reference CPU baseline not available: %r" % (ex,))
+                finally:
+                    shutil.rmtree(td, ignore_errors=True)
             del cb, co
         if not args.no_host_io:  # the boundary's host-buffer forms (SURVEY 8d's metric includes H2D of reads and D2H of results)
             hb_pin = ca.pinned_array(n_bases)                # the chunk an integration reads its input into (cs_host_alloc)

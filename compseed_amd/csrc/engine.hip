@@ -788,9 +788,9 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
 				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
-				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
 				                              (const BTask *)e->d_bq.p, cn, C + 5);
-				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
 				                        (const BTask *)e->d_bq.p, cn, C + 5);
 				if (A.win) // the calls without stored LEPs, beside the others on the same side stream, behind the handful of wide sweeps
 					LAUNCH_CT(count, bwd_win0_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), e->stream3, A,

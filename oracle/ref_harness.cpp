@@ -24,6 +24,9 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 #include "bwalib/bwa.h"
 #include "FM_index/bwt.h"
@@ -170,6 +173,57 @@ static void dump_prims(const bwt_t *bwt, const char *fn, long n, uint64_t seed, 
 	fclose(fp);
 }
 
+// --time T: the reference's own seeding + SAL code (CompSeed flow: collect_mem_with_sst / tem_forward_sst with SSTs cleared per 512 reads,
+// then the SAL block of comp_seed.cpp:2306-2347) on T threads, each with its own thread_aux_t, 512-read batches handed out by a counter --
+// what kt_for does in mem_process_seqs (comp_seed.cpp:2541-2548), without chaining / extension / SAM.  Prints reads per second.
+static int time_mode(const mem_opt_t *opt, const bwt_t *bwt, const std::vector<std::string> &reads, int T)
+{
+	const size_t n = reads.size(), nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
+	std::atomic<size_t> next(0);
+	std::atomic<uint64_t> tot_mems(0), tot_seeds(0);
+	auto work = [&]() {
+		thread_aux_t aux;
+		aux.forward_sst = new SST(bwt); aux.backward_sst = new SST(bwt);
+		std::vector<bwtintv_t> B; std::vector<std::vector<bwtintv_t>> match(BATCH_SIZE);
+		uint64_t nm = 0, ns = 0;
+		for (size_t b = next++; b < nb; b = next++) {
+			const size_t b0 = b * BATCH_SIZE, b1 = std::min(n, b0 + (size_t)BATCH_SIZE);
+			aux.forward_sst->clear(); aux.backward_sst->clear();
+			for (size_t r = b0; r < b1; r++) {
+				std::vector<uint8_t> seq(reads[r].size() + 1, 4);
+				const int len = (int)reads[r].size();
+				for (int j = 0; j < len; j++) seq[j] = nst_nt4_table[(uint8_t)reads[r][j]];
+				path_compseed(opt, len, seq.data(), aux, match[r - b0]);
+				nm += match[r - b0].size();
+			}
+			std::vector<sal_request_t> uniq; std::vector<uint64_t> slots;
+			for (size_t r = b0; r < b1; r++)
+				for (const auto &m : match[r - b0]) {
+					uint64_t step = m.x[2] > (uint64_t)opt->max_occ ? m.x[2] / opt->max_occ : 1;
+					for (uint64_t k = 0, count = 0; k < m.x[2] && count < (uint64_t)opt->max_occ; k += step, count++) { slots.push_back(m.x[0] + k); uniq.emplace_back(sal_request_t(m.x[0] + k)); }
+				}
+			std::sort(uniq.begin(), uniq.end());
+			size_t sz = 0;
+			for (size_t i = 0; i < uniq.size(); i++) if (i == 0 or uniq[i - 1].que_location != uniq[i].que_location) uniq[sz++] = uniq[i];
+			uniq.resize(sz);
+			for (uint64_t q : slots) {
+				auto k = std::lower_bound(uniq.begin(), uniq.end(), sal_request_t(q));
+				if (k->coordinate == (uint64_t)-1) k->coordinate = bwt_sa(bwt, q);
+			}
+			ns += slots.size();
+		}
+		tot_mems += nm; tot_seeds += ns;
+		delete aux.forward_sst; delete aux.backward_sst;
+	};
+	const auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++) th.emplace_back(work);
+	for (auto &t : th) t.join();
+	const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	printf("{\"reads\": %zu, \"threads\": %d, \"seconds\": %.3f, \"reads_per_s\": %.1f, \"mems\": %lu, \"seeds\": %lu}\n", n, T, sec, n / sec, (unsigned long)tot_mems.load(), (unsigned long)tot_seeds.load());
+	return 0;
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 4) {
@@ -178,7 +232,7 @@ int main(int argc, char **argv)
 	}
 	mem_opt_t *opt = mem_opt_init();
 	int batch = BATCH_SIZE;
-	const char *prim_fn = 0, *chain_fn = 0; long prim_n = 0; uint64_t prim_seed = 1;
+	const char *prim_fn = 0, *chain_fn = 0; long prim_n = 0; uint64_t prim_seed = 1; int time_threads = 0;
 	for (int i = 4; i < argc; i++) {
 		std::string a = argv[i];
 		if (a == "-k") opt->min_seed_len = atoi(argv[++i]);
@@ -189,6 +243,7 @@ int main(int argc, char **argv)
 		else if (a == "-B") batch = atoi(argv[++i]);
 		else if (a == "--prim") { prim_fn = argv[++i]; prim_n = atol(argv[++i]); prim_seed = strtoull(argv[++i], 0, 10); }
 		else if (a == "--chains") chain_fn = argv[++i];
+		else if (a == "--time") time_threads = atoi(argv[++i]);
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
 	}
 	if (batch < 1 || batch > BATCH_SIZE) { fprintf(stderr, "batch must be in [1,%d]\n", BATCH_SIZE); return 1; }
@@ -207,6 +262,7 @@ int main(int argc, char **argv)
 		fclose(fp);
 	}
 	size_t n = reads.size();
+	if (time_threads > 0) return time_mode(opt, bwt, reads, time_threads);
 
 	thread_aux_t aux;
 	aux.forward_sst = new SST(bwt);
