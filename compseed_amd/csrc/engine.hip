@@ -117,8 +117,8 @@ struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
 	cs_engine_options_t opt{};
-	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr; // stream2: round 3 (low priority); stream3: wide sweeps + calls without LEPs
-	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr;
+	hipStream_t stream = nullptr, stream2 = nullptr, stream3 = nullptr, stream4 = nullptr; // stream2: round 3 (low priority); stream3: calls without LEPs; stream4: wide sweeps
+	hipEvent_t ev_r3a = nullptr, ev_r3b = nullptr, ev_wa = nullptr, ev_wb = nullptr, ev_wc = nullptr;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 	DevIndex ix{};
 	DevBuf<uint4> d_bwt; DevBuf<uint64_t> d_sa;
@@ -254,11 +254,14 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 		HIP_TRY(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_wa, hipEventDisableTiming));
 		HIP_TRY(hipEventCreateWithFlags(&e->ev_wb, hipEventDisableTiming));
+		HIP_TRY(hipStreamCreateWithFlags(&e->stream4, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&e->ev_wc, hipEventDisableTiming));
 		// The runtime multiplexes the normal-priority streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
 		// default), and a stream that shares its queue with a 30-ms download stands still for 30 ms -- measured: the seeding kernels
 		// of a sub-batch took 65 instead of 45 ms beside the download of the previous one.  So the engine keeps to three normal
-		// streams (main, side, upload), round 3 runs at low and the downloads at high priority, which have queues of their own.
-		HIP_TRY(hipStreamCreateWithFlags(&e->s_up, hipStreamNonBlocking));
+		// streams (main and two side streams; with the process's default stream that makes four); round 3 runs at low priority and
+		// the two copy streams at high priority, which have queues of their own.
+		HIP_TRY(hipStreamCreateWithPriority(&e->s_up, hipStreamNonBlocking, hi));
 		HIP_TRY(hipStreamCreateWithPriority(&e->s_down, hipStreamNonBlocking, hi));
 		for (auto &ev : e->hp_ev_pk) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		for (auto &ev : e->hp_ev_dn) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -460,6 +463,8 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	if (e->ev_wa) (void)hipEventDestroy(e->ev_wa);
 	if (e->ev_wb) (void)hipEventDestroy(e->ev_wb);
 	if (e->stream3) (void)hipStreamDestroy(e->stream3);
+	if (e->ev_wc) (void)hipEventDestroy(e->ev_wc);
+	if (e->stream4) (void)hipStreamDestroy(e->stream4);
 	if (e->stream2) (void)hipStreamDestroy(e->stream2);
 	if (e->stream) (void)hipStreamDestroy(e->stream);
 	delete e;
@@ -674,7 +679,7 @@ static int run_smem_split(cs_engine *e, const cs_params_t *par, const uint64_t *
 	const int rc = run_smem_split_body(e, par, d_off, nb, max_len, n_ovf_out);
 	if (rc != CS_OK) { // every early exit: kernels on the side streams may still be appending to buffers the next call reuses
 		const std::string keep = g_err;
-		(void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
+		(void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3); (void)hipStreamSynchronize(e->stream4);
 		(void)hipGetLastError();
 		g_err = keep;
 	}
@@ -788,11 +793,15 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
 				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
-				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				// side streams: the calls with more than 46 / 64 LEPs, one wave each (few on a mostly unique genome, many on a repeat-rich one:
+				// four blocks per CU so that they overlap their list reads), and the calls without stored LEPs (the bulk of the calls)
+				HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
+				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
 				                              (const BTask *)e->d_bq.p, cn, C + 5);
-				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream3, A,
+				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
 				                        (const BTask *)e->d_bq.p, cn, C + 5);
-				if (A.win) // the calls without stored LEPs, beside the others on the same side stream, behind the handful of wide sweeps
+				HIP_TRY(hipEventRecord(e->ev_wc, e->stream4));
+				if (A.win)
 					LAUNCH_CT(count, bwd_win0_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * win0_occ, (cn + 255) / 256)), e->stream3, A,
 					          (const BTask *)e->d_bq.p, cn);
 				HIP_TRY(hipEventRecord(e->ev_wb, e->stream3));
@@ -800,6 +809,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				else LAUNCH_CT(count, bwd_all_kernel, dim3((unsigned)std::min<uint64_t>(cap_blocks, (cn + 15) / 16)), s, A, (const BTask *)e->d_bq.p, cn, C + 2);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamWaitEvent(s, e->ev_wb, 0)); // all must be done before the slots and the LEP arena are reused
+				HIP_TRY(hipStreamWaitEvent(s, e->ev_wc, 0));
 			}
 			c0 += cn;
 		}
