@@ -335,6 +335,25 @@ def test_cli_dump_matches_golden(tmp_path):
     assert "BWT-extend:" in r.stderr and "SA Lookup:" in r.stderr
 
 
+def test_cli_shards_over_two_gpus_when_present(tmp_path):
+    """compseed_amd_cli --gpus 2: every chunk split into two contiguous read ranges, one engine per GPU; same dump as with one GPU
+    (skipped on a one-GPU box; torch.cuda.device_count() does not initialise the runtime here)"""
+    import subprocess
+    import torch
+    import compseed_amd as ca
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    cli = os.path.join(os.path.dirname(ca.lib_path()), "compseed_amd_cli")
+    outs = []
+    for g in ("1", "2"):
+        out = tmp_path / ("seeds%s.txt" % g)
+        r = subprocess.run([cli, "-K", "30000", "--gpus", g, "--dump-seeds", str(out), _data.PREFIX, os.path.join(_data.GOLD, "main100.txt")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") > 10000
+
+
 def test_device_sst_is_transparent(eng):
     """sst_mode switches the LDS-resident memo of bwt_extend on and off: identical seeds, fewer real calls when on
     (the cache only memoises a pure function -- SURVEY Appendix B.1 -- so the A/B is a built-in test)"""
