@@ -127,7 +127,7 @@ struct cs_engine {
 	DevBuf<uint64_t> d_bloom; int bloom_k = 0; uint32_t bloom_bits = 0; // k-mer filter of the text for the min_seed_len in use (built on first use)
 	DevBuf<uint32_t> d_cnt_snap; DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
 	// inputs
-	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off;
+	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off; DevBuf<uint4> d_seqp; const uint64_t *off_base = nullptr; // d_seqp: pack_reads_kernel's records for the batch whose offsets start at off_base
 	// SMEM stage
 	DevBuf<OutMem> d_out, d_out2; DevBuf<uint32_t> d_cnt, d_cnt2, d_ovf; DevBuf<uint4> d_spill;
 	DevBuf<unsigned long long> d_ctr; // [0] task counter, [1] queries, [2] overflow count, [3] max len
@@ -441,7 +441,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	(void)hipSetDevice(e->device);
 	pipe_stop(e);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_seqp.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
@@ -708,6 +708,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 
 	SplitArgs A;
 	A.ix = e->ix; A.seq = e->d_seq.p; A.off = d_off; A.n_reads = nb;
+	A.seqp = e->d_seqp.p + (d_off - e->off_base); // record index = (off[r] >> 5) + r with r counted from the batch's first read
 	if (dis & CS_DISABLE_TEXT_MODE) A.ix.text2 = nullptr;
 	A.out = e->d_out.p; A.out_cnt = e->d_cnt.p; A.cap = e->cap;
 	A.ovf = e->d_ovfrec.p; A.ovf_cnt = C + 6; A.ovf_cap = ovf_cap;
@@ -880,6 +881,12 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		hipLaunchKernelGGL(nt4_kernel, dim3(g), dim3(256), 0, s, d_bases, e->d_seq.p, n_bases);
 	}
 	HIP_TRY(hipMemsetAsync(e->d_seq.p + n_bases, 4, 64, s));
+	if (e->smem_mode == 1) { // the split kernels read the packed copy (32 bases per 16-byte record)
+		CS_TRY(e->d_seqp.reserve((size_t)(n_bases >> 5) + (size_t)n_reads + 4));
+		hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads * 8, 256), (int64_t)e->n_cu * 16)), dim3(256), 0, s, e->d_seq.p, d_off, n_reads, e->d_seqp.p);
+		e->off_base = d_off;
+		e->stream_bytes += n_bases + 16 * ((n_bases >> 5) + (uint64_t)n_reads);
+	}
 
 	const uint32_t cap = e->cap;
 	int64_t per_launch = (int64_t)std::max<size_t>(1024, e->max_raw_bytes / ((size_t)cap * sizeof(OutMem)));

@@ -48,6 +48,7 @@ struct OvfRec { OutMem m; uint32_t r, pad; };                              // a 
 struct SplitArgs {
 	DevIndex ix;
 	const uint8_t  *seq;
+	const uint4    *seqp;                             // the reads as 16-byte records of 32 bases (pack_reads_kernel), already offset to this launch's first read
 	const uint64_t *off;
 	int64_t   n_reads;
 	OutMem   *out; uint32_t *out_cnt; uint32_t cap;
@@ -268,6 +269,98 @@ template <int DIR> struct BaseReader {
 	}
 };
 
+// The reads a second time, packed: one 16-byte record per 32 bases -- .x/.y the bases, 2 bits each, base j in bits 2j..2j+1 (the
+// order of the 2-bit text), .z one bit per base that is ambiguous or lies behind the end of the read.  Record k of read r is
+// rec[(off[r] >> 5) + r + k]: no second offset array, and read r owns at least len/32 + 1 records, so the record of position
+// len exists and says "end" there.  Why: at 6-8 waves per SIMD the lanes in flight touch more lines than the L2 holds, so every
+// 8-byte window of a byte-per-base read and every 4-byte word of the text came from HBM again (fwd0_kernel fetched 30 lines per
+// read for 12 lines' worth of data); with 32 bases per load there is one fetch per record.
+__global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64_t n_reads, uint4 *rec)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+	for (uint64_t r = gid >> 3; r < (uint64_t)n_reads; r += gstride) { // eight lanes per read, a record each
+		const uint64_t rb = off[r], re = off[r + 1], len = re - rb;
+		const uint64_t w0 = (rb >> 5) + r, nrec = (re >> 5) + r + 1 - w0;
+		for (uint64_t k = gid & 7; k < nrec; k += 8) {
+			uint4 o = {0u, 0u, ~0u, 0u};
+			if (k * 32 < len) {
+				const uint64_t a = rb + k * 32, a0 = a & ~7ull;                // (the nt4 copy is padded by 64 bytes)
+				const uint64_t *w = reinterpret_cast<const uint64_t *>(seq + a0);
+				const uint32_t sh = (uint32_t)(a - a0) << 3;
+				uint64_t v[5];
+#pragma unroll
+				for (int q = 0; q < 5; ++q) v[q] = w[q];
+				uint64_t bases = 0; uint32_t bad = 0;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					uint64_t b8 = sh ? (v[q] >> sh) | (v[q + 1] << (64u - sh)) : v[q]; // bases 8q .. 8q+7, a byte each
+					bad |= (uint32_t)((((b8 >> 2) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * q);
+					b8 &= 0x0303030303030303ull;
+					b8 = (b8 | (b8 >> 6)) & 0x000F000F000F000Full;
+					b8 = (b8 | (b8 >> 12)) & 0x000000FF000000FFull;
+					bases |= ((b8 | (b8 >> 24)) & 0xFFFFull) << (16 * q);
+				}
+				const uint64_t left = len - k * 32;
+				if (left < 32) { bad |= ~0u << (uint32_t)left; bases &= (1ull << (2 * (uint32_t)left)) - 1ull; }
+				o.x = (uint32_t)bases; o.y = (uint32_t)(bases >> 32); o.z = bad;
+			}
+			rec[w0 + k] = o;
+		}
+	}
+}
+// reader over those records: any position of the read, one load per record entered
+struct PackedReader {
+	const uint4 *rec; uint64_t bases; uint32_t bad; int wk;
+	__device__ __forceinline__ void load() { const uint4 v = rec[wk]; bases = (uint64_t)v.x | (uint64_t)v.y << 32; bad = v.z; }
+	__device__ __forceinline__ void start(const uint4 *recs, uint64_t rb, uint32_t r, int pos)
+	{
+		rec = recs + (rb >> 5) + r; wk = (pos < 0 ? 0 : pos) >> 5; load();
+	}
+	__device__ __forceinline__ void seek(int pos) { if ((pos >> 5) != wk) { wk = pos >> 5; load(); } }
+	__device__ __forceinline__ uint32_t at(int pos) // 0..3, or 4: ambiguous base / behind the end (pos <= len)
+	{
+		seek(pos);
+		const uint32_t j = (uint32_t)pos & 31u;
+		return (bad >> j) & 1u ? 4u : (uint32_t)(bases >> (j << 1)) & 3u;
+	}
+	// the jk (<= 16) bases from pos on as a jump-table code (first base most significant); pos + jk <= len
+	__device__ __forceinline__ uint32_t kmer(int pos, int jk, uint32_t &badk)
+	{
+		seek(pos);
+		const uint32_t j = (uint32_t)pos & 31u;
+		uint64_t w = bases >> (j << 1); uint32_t bd = bad >> j;
+		if (j + (uint32_t)jk > 32u) { // j >= 17: the code runs into the next record (left loaded: the caller goes on from there)
+			++wk; load();
+			w |= bases << ((32u - j) << 1); bd |= bad << (32u - j);
+		}
+		badk = (bd & ((1u << jk) - 1u)) ? 4u : 0u;
+		uint32_t rv = __brev((uint32_t)w);                           // group q at 2(15-q), its two bits swapped
+		rv = ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
+		return rv >> (32 - 2 * jk);
+	}
+};
+// text mode: up to 32 read bases from i against the text from tpos (<= seq_len); true when the match ends here.  Counts what the
+// reference would have performed: one bwt_extend per base that is compared (the last one, at a mismatch or the text's end, returns
+// size 0); none at an ambiguous base or the read's end (bwt.c:309-316).
+template <class WC>
+__device__ __forceinline__ bool text_step(const DevIndex &ix, PackedReader &rd, int &i, uint64_t &tpos, uint32_t &my_q, uint32_t &my_hits, WC &W)
+{
+	rd.seek(i);
+	const uint32_t j = (uint32_t)i & 31u, avail = 32u - j;
+	const uint64_t x = (rd.bases >> (j << 1)) ^ text_win(ix, tpos); wc_add(W, EV_TEXT, 4u);
+	const uint64_t d = (x | x >> 1) & 0x5555555555555555ull;
+	uint32_t m = d ? (uint32_t)(__ffsll((long long)d) - 1) >> 1 : 32u;   // first base that differs
+	const uint64_t room = ix.seq_len - tpos;
+	if (room < m) m = (uint32_t)room;                                    // ... or has no text base to agree with
+	const uint32_t bb = rd.bad >> j, m_bad = bb ? (uint32_t)__ffs((int)bb) - 1u : 32u;
+	uint32_t n = m < m_bad ? m : m_bad;
+	if (n > avail) n = avail;
+	i += (int)n; tpos += n; my_q += n; my_hits += n;
+	if (n == avail) return false;                                        // the record is used up: on with the next one
+	if (n != m_bad) { ++my_q; ++my_hits; }
+	return true;
+}
+
 // The jk (<= 16) read bases from byte address a on, packed 2 bits each, first base most significant (as jump_fill_kernel
 // numbers k-mers), without a per-base loop: three aligned 8-byte words, funnelled into two, each word's eight 2-bit codes
 // squeezed together by three shift-or-mask steps, then the order of the 2-bit groups reversed.  bad > 3: an ambiguous base.
@@ -348,6 +441,14 @@ __device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r,
 {
 	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
 	while (x < len && A.seq[rb + x] > 3) ++x;
+	uint32_t d = (x == ret && ret - x_cur < 16382) ? (uint32_t)(ret - x_cur) : 0u;
+	return x < len ? ftask_pack(r, (uint32_t)x, 1u + d, TK_ROUND1) : FTASK_NONE;
+}
+
+__device__ __forceinline__ uint64_t chain_round1(PackedReader &rd, uint32_t r, int len, int ret, int x_cur) // the same over the packed read
+{
+	int x = ret;
+	while (x < len && rd.at(x) > 3) ++x;
 	uint32_t d = (x == ret && ret - x_cur < 16382) ? (uint32_t)(ret - x_cur) : 0u;
 	return x < len ? ftask_pack(r, (uint32_t)x, 1u + d, TK_ROUND1) : FTASK_NONE;
 }
@@ -548,10 +649,10 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 	const DevIndex &ix = A.ix;
 	const int jk = A.jump_k;
 	bool active = false, textm = false;
-	uint32_t r = 0, tw = 0;
+	uint32_t r = 0;
 	int len = 0, i = 0;
 	Intv ik = {0, 0, 0};
-	BaseReader<1> rd;
+	PackedReader rd;
 	uint32_t my_q = 0, my_hits = 0;
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
@@ -565,13 +666,13 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 			if ((uint32_t)(t >> 62) == TK_ROUND1 && ((t >> 32) & 0xffffu) == 0 && (int64_t)r < A.n_reads) {
 				const uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
 				if (len >= jk) {
-					uint32_t bad; const uint32_t code = kmer_code(A.seq, rb, jk, bad);
+					rd.start(A.seqp, rb, r, 0);
+					uint32_t bad; const uint32_t code = rd.kmer(0, jk, bad);
 					uint32_t e; unpack_lep(A.jump[code], ik, e); wc_add(W, EV_JUMP);
 					if (bad <= 3 && ik.x2 > 0) {
 						fq[t_id] = FTASK_NONE;                       // ours
 						i = jk; textm = false; active = true;
 						my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
-						rd.start(A.seq, rb, i);
 					}
 				}
 			}
@@ -582,15 +683,7 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 			bool fin = false;
 			if (textm) { // as in fwd_kernel: the unique match against the 2-bit text, cursor in ik.x1
 				uint64_t tpos = ik.x1;
-				for (int q = 0; q < 8; ++q) {
-					uint32_t b = i < len ? rd.at(i) : 4u;
-					if (b > 3) { fin = true; break; }
-					++my_q; ++my_hits;
-					uint32_t tb = tpos < ix.seq_len ? (tw >> ((uint32_t)(tpos & 15) << 1)) & 3u : 4u;
-					if (tb != b) { fin = true; break; }
-					++i; ++tpos;
-					if ((tpos & 15) == 0) { tw = ix.text2[tpos >> 4]; wc_add(W, EV_TEXT); }
-				}
+				fin = text_step(ix, rd, i, tpos, my_q, my_hits, W);
 				ik.x1 = tpos;
 				if (fin) { ik.x1 = isa_direct(ix, ix.seq_len - tpos); wc_add(W, EV_ISA); }
 			} else {
@@ -605,14 +698,14 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 						if (ik.x2 == 1) {
 							const uint64_t tp = sa_direct(ix, ik.x0) + (uint64_t)i;
 							wc_add(W, EV_SA);
-							if (tp <= ix.seq_len) { textm = true; ik.x1 = tp; tw = ix.text2[tp >> 4]; wc_add(W, EV_TEXT); } // (always: the match lies inside the text)
+							if (tp <= ix.seq_len) { textm = true; ik.x1 = tp; } // (always: the match lies inside the text)
 						}
 					}
 				}
 			}
 			if (fin) { // the call's only SMEM is its longest forward match (bwt.c:325 starts the sweep at -1)
 				push0 = emit_smem(A, r, TK_ROUND1, ik, 0, (uint32_t)i, aux0);
-				push1 = chain_round1(A, r, i, 0);
+				push1 = chain_round1(rd, r, len, i, 0);
 				active = false;
 			}
 		}
