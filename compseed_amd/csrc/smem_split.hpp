@@ -323,6 +323,16 @@ struct PackedReader {
 		const uint32_t j = (uint32_t)pos & 31u;
 		return (bad >> j) & 1u ? 4u : (uint32_t)(bases >> (j << 1)) & 3u;
 	}
+	// the 32 bases from pos on (2 bits each, the first least significant) and their ambiguity bits; the nb (<= 32) first of them must
+	// lie inside the read.  The reader stays on the record of pos.
+	__device__ __forceinline__ uint64_t window(int pos, int nb, uint32_t &badw)
+	{
+		seek(pos);
+		const uint32_t j = (uint32_t)pos & 31u;
+		uint64_t w = bases >> (j << 1); badw = bad >> j;
+		if (j + (uint32_t)nb > 32u) { const uint4 v = rec[wk + 1]; w |= ((uint64_t)v.x | (uint64_t)v.y << 32) << ((32u - j) << 1); badw |= v.z << (32u - j); }
+		return w;
+	}
 	// the jk (<= 16) bases from pos on as a jump-table code (first base most significant); pos + jk <= len
 	__device__ __forceinline__ uint32_t kmer(int pos, int jk, uint32_t &badk)
 	{
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 	uint64_t tslot = 0; uint32_t r = 0, kind = 0, min_intv = 1, dprev = 0;
 	int len = 0, x = 0, i = 0, n = 0;
 	Intv ik = {0, 0, 0};
-	BaseReader<1> rd;
+	PackedReader rd;
 	uint4 *lep = nullptr;
 	uint32_t my_q = 0, my_hits = 0, my_sw = 0; // per-lane counters (a lane sees a few thousand extensions at most); bit 31 of my_sw: created a backward task
 	WavePool P = {0, 0, false};
@@ -477,20 +487,18 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 	// bases per iteration without touching the index, and at the end takes the reverse-strand coordinate from the inverse
 	// suffix array (the forward coordinate of a unique match does not move).  Two random reads replace ~80 per read.
 	const bool text_on = use_sst && ix.text2 != nullptr;
-	uint32_t tw = 0; // text mode (kind == TK_TEXT): the 16 text bases around the cursor; the cursor itself lives in ik.x1
+	// (text mode is kind == TK_TEXT; the text cursor lives in ik.x1)
 	const int jump_k = (use_sst && A.jump && A.jump_k <= A.min_seed_len) ? A.jump_k : 0;
 	// start a round-3 segment at x: through the jump table when the next jump_k bases are all A/C/G/T, else base by base
 	auto r3_start = [&]() -> bool { // true: the jump table was used
 		if (jump_k && x + jump_k <= len) {
-			uint32_t code = 0; bool clean = true;
-			for (int q = 0; q < jump_k; ++q) { uint32_t bq = rd.at(x + q); clean = clean && bq <= 3; code = code << 2 | (bq & 3); }
-			if (clean) {
+			uint32_t bad; const uint32_t code = rd.kmer(x, jump_k, bad);
+			if (bad == 0) {
 				uint32_t e; unpack_lep(A.jump[code], ik, e); wc_add(W, EV_JUMP);
 				i = x + jump_k; slen = jump_k; scode = 0;
 				my_q += (unsigned)(jump_k - 1); my_hits += (unsigned)(jump_k - 1);
 				return true;
 			}
-			rd.start(A.seq, A.off[r], x); // the reader only moves forward: rewind it to the segment start
 		}
 		scode = rd.at(x); slen = 1;
 		ik = set_intv(ix, (int)scode); i = x + 1;
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 			if (kind != TK_NOP && (int64_t)r < A.n_reads) {
 				uint64_t rb = A.off[r]; len = (int)(A.off[r + 1] - rb);
 				if (x < len) {
-					rd.start(A.seq, rb, x);
+					rd.start(A.seqp, rb, r, x);
 					lep = A.lep + tslot * A.lep_stride; n = 0;
 					if (kind == TK_ROUND3) while (x < len && rd.at(x) > 3) ++x; // first start (bwamem.c:255-256)
 					if (x < len) {
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 							bool start = true;
 							if (((x == 0 && kind == TK_ROUND1) || A.win) && jump_k) {
 								start = false;
-								if (r3_start() && ik.x2 < min_intv) { my_q -= (unsigned)(jump_k - 1); my_hits -= (unsigned)(jump_k - 1); rd.start(A.seq, rb, x); start = true; }
+								if (r3_start() && ik.x2 < min_intv) { my_q -= (unsigned)(jump_k - 1); my_hits -= (unsigned)(jump_k - 1); start = true; }
 							}
 							if (start) { scode = rd.at(x); slen = 1; ik = set_intv(ix, (int)scode); i = x + 1; }
 						}
@@ -537,15 +545,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 			bool fin = false; // the forward pass of an SMEM call ends in this iteration with ik = [x, i)
 			if (kind == TK_TEXT) {
 				uint64_t tpos = ik.x1;
-				for (int q = 0; q < 8; ++q) {
-					uint32_t b = i < len ? rd.at(i) : 4u;
-					if (b > 3) { fin = true; break; }                      // read end or ambiguous base: no extension is attempted
-					++my_q; ++my_hits;                                     // the bwt_extend the reference performs here
-					uint32_t tb = tpos < ix.seq_len ? (tw >> ((uint32_t)(tpos & 15) << 1)) & 3u : 4u;
-					if (tb != b) { fin = true; break; }                    // mismatch or text end: that extension returns size 0
-					++i; ++tpos;
-					if ((tpos & 15) == 0) { tw = ix.text2[tpos >> 4]; wc_add(W, EV_TEXT); } // padded: readable up to and including seq_len
-				}
+				fin = text_step(ix, rd, i, tpos, my_q, my_hits, W);        // up to 32 bases against the text
 				ik.x1 = tpos;
 				if (fin) {
 					ik.x1 = isa_direct(ix, ix.seq_len - tpos); kind = TK_ROUND1; // rank of the reverse complement of [x, i)
@@ -558,16 +558,19 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 						const int nb = (int)dprev - 1;
 						const uint64_t px = tpos - (uint64_t)(i - x); // text position of read base x
 						bool same = px >= (uint64_t)nb;
-						const uint64_t rbase = A.off[r];
-						wc_add(W, EV_TEXT, 2u); // (the dprev - 1 bases in front of the pivot: one or two words of the text)
-						for (int q = 1; same && q <= nb; ++q) {
-							uint64_t tp = px - (uint64_t)q;
-							same = ((ix.text2[tp >> 4] >> ((uint32_t)(tp & 15) << 1)) & 3u) == (uint32_t)A.seq[rbase + (uint64_t)(x - q)];
+						for (int done = 0; same && done < nb;) { // read [x - nb, x) against the text in front of px, a record at a time
+							const int p = x - nb + done;
+							rd.seek(p);
+							const uint32_t j = (uint32_t)p & 31u, room = 32u - j, n = (uint32_t)(nb - done) < room ? (uint32_t)(nb - done) : room;
+							const uint64_t dx = (rd.bases >> (j << 1)) ^ text_win(ix, px - (uint64_t)(nb - done)); wc_add(W, EV_TEXT, 4u);
+							const uint64_t keep = n >= 32u ? ~0ull : (1ull << (n << 1)) - 1ull;
+							same = (dx & keep) == 0 && ((rd.bad >> j) & (uint32_t)(n >= 32u ? ~0u : (1u << n) - 1u)) == 0;
+							done += (int)n;
 						}
 						if (same) {
 							Intv m = {isa_direct(ix, px - (uint64_t)nb), ik.x1, 1}; wc_add(W, EV_ISA);
 							push0 = emit_smem(A, r, TK_ROUND1, m, x - nb, (uint32_t)i, aux0);
-							push1 = chain_round1(A, r, i, x);
+							push1 = chain_round1(rd, r, len, i, x);
 							++my_sw; active = false; fin = false;
 						}
 					}
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 						if (text_on && ik.x2 == 1 && kind == TK_ROUND1) { // unique from here on: continue on the text
 							const uint64_t tp = sa_direct(ix, ik.x0) + (uint64_t)(i - x); // text cursor: the base that has to equal read base i
 							wc_add(W, EV_SA);
-							if (tp <= ix.seq_len) { kind = TK_TEXT; ik.x1 = tp; tw = ix.text2[tp >> 4]; wc_add(W, EV_TEXT); }  // (always: the match lies inside the text)
+							if (tp <= ix.seq_len) { kind = TK_TEXT; ik.x1 = tp; }  // (always: the match lies inside the text)
 						}
 					}
 				}
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 				// forward match, so it needs no LEP list, no backward task, and finishes right here.
 				if (x == 0) {
 					push0 = emit_smem(A, r, kind, ik, 0, (uint32_t)i, aux0);
-					if (kind == TK_ROUND1) push1 = chain_round1(A, r, i, x);
+					if (kind == TK_ROUND1) push1 = chain_round1(rd, r, len, i, x);
 				} else { // hand the list to the backward kernel of its size class; ret = end of the longest match = next pivot
 					if (!A.win || i - x >= A.min_seed_len) { lep[n++] = pack_lep(ik, (uint32_t)i); wc_add(W, EV_LEP); }
 					uint32_t cls = n <= 16 ? 0u : n <= 32 ? 1u : n <= 64 ? 2u : 3u;
@@ -856,21 +859,21 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 //
 // A group of G lanes per call: lanes 0..17 take the ends x+1 .. x+18, lanes 18.. take the stored LEPs in ascending order.
 template <class WC>
-__device__ __forceinline__ bool win_lane_init(const SplitArgs &A, uint32_t gl, uint64_t rb, int x, int ret, uint32_t min_intv,
+__device__ __forceinline__ bool win_lane_init(const SplitArgs &A, PackedReader &rd, uint32_t gl, int x, int ret, uint32_t min_intv,
                                               Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits, WC &W)
 {
-	const int k = A.min_seed_len, jk = A.jump_k;
+	const int k = A.min_seed_len, jk = A.jump_k; // jk <= k <= 24 (the window scheme's range)
 	const int te = x + 1 + (int)gl;
 	if ((int)gl >= k - 1 || te > ret || te - k < 0) return false;
+	uint32_t badw;
+	const uint64_t w = rd.window(te - k, k, badw); // the k-mer [te - k, te): its last jk bases are the jump-table code
+	if (badw & ((1u << k) - 1u)) return false;     // an ambiguous base inside the window: this end cannot reach min_seed_len
 	if (A.bloom) { // does the min_seed_len-mer [te - k, te) occur at all?
-		uint32_t badk;
-		const uint64_t ck = kmer_code_lsb(A.seq, rb + (uint64_t)(te - k), k, badk);
 		wc_add(W, EV_BLOOM);
-		if (badk > 3 || !kmer_filter_has(A.bloom, A.bloom_bits, ck)) return false;
+		if (!kmer_filter_has(A.bloom, A.bloom_bits, w & ((1ull << (2 * k)) - 1ull))) return false;
 	}
-	uint32_t bad;
-	const uint32_t code = kmer_code(A.seq, rb + (uint64_t)(te - jk), jk, bad);
-	if (bad > 3) return false; // an ambiguous base inside the window: this end cannot reach min_seed_len
+	uint32_t code = __brev((uint32_t)(w >> (2 * (k - jk))));       // group q at 2(15-q), its two bits swapped
+	code = (((code & 0xAAAAAAAAu) >> 1) | ((code & 0x55555555u) << 1)) >> (32 - 2 * jk);
 	uint32_t dummy; unpack_lep(A.jump[code], e, dummy); wc_add(W, EV_JUMP);
 	my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
 	if (e.x2 < min_intv) return false;
@@ -890,7 +893,7 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 	uint32_t r = 0, kind = 0, min_intv = 1, pend = 0;
 	int s = 0, f = 0, ret = 0, xp = 0, clk = 0;
 	Intv e = {0, 0, 0};
-	BaseReader<-1> rd;
+	PackedReader rd;
 	uint64_t batch_base = 0, avail_m = 0; bool exhausted = false;
 	for (;;) { // task acquisition exactly as in bwd_groups_run
 		uint64_t idle_m = __ballot(!active && gl == 0);
@@ -922,14 +925,14 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 				const int n = bt.n;
 				const uint64_t rb = A.off[r];
 				f = 0x7fffffff;
-				if (gl < (uint32_t)WIN_LANES) valid = win_lane_init(A, gl, rb, xp, ret, min_intv, e, pend, s, my_q, my_hits, W);
+				rd.start(A.seqp, rb, r, xp);
+				if (gl < (uint32_t)WIN_LANES) valid = win_lane_init(A, rd, gl, xp, ret, min_intv, e, pend, s, my_q, my_hits, W);
 				else {
 					int j = (int)gl - WIN_LANES;
 					valid = j < n;
 					if (valid) { unpack_lep(A.lep[(size_t)t * A.lep_stride + j], e, pend); s = xp - 1; wc_add(W, EV_LEP); }
 				}
 				walking = valid;
-				if (valid) rd.start(A.seq, rb, s);
 				clk = xp + WIN_LANES - A.jump_k - 1; // the base in front of the last window lane, the first to join
 				if (clk < xp - 1) clk = xp - 1;        // (the LEP lanes join at the pivot)
 				active = true;
@@ -967,7 +970,7 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 				int src = higher ? __ffsll((long long)higher) - 1 : (int)lane;
 				int fn = __shfl(f, src);
 				if (valid && (higher == 0 || f < fn)) push0 = emit_smem(A, r, kind, e, f + 1, pend, aux0);
-				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(A, r, ret, xp);
+				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(rd, r, (int)(A.off[r + 1] - A.off[r]), ret, xp);
 				active = false; valid = false;
 			}
 		}
@@ -1007,10 +1010,10 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 		BTask bt = bq[t];
 		uint32_t r = bt.r, kind = bt.mi_kind >> 14, min_intv = bt.mi_kind & 0x3fffu;
 		uint4 *lep = A.lep + (size_t)t * A.lep_stride;
-		uint64_t rb = A.off[r];
+		PackedReader rd; rd.start(A.seqp, A.off[r], r, (int)bt.x - 1);
 		int n = bt.n, lo = 0, nm = 0, last_start = 0, f_long = 0x7fffffff;
 		for (int i = (int)bt.x - 1; i >= -1; --i) {
-			uint32_t b = i < 0 ? 4u : A.seq[rb + i];
+			uint32_t b = i < 0 ? 4u : rd.at(i);
 			int w = n; bool first_done = false, have_prev = false; uint64_t prev_carry = 0, push0 = FTASK_NONE, aux0 = AUX_NONE;
 			for (int top = n; top > lo; top -= 64) {
 				int j = top - 1 - (int)lane; bool valid = j >= lo;
@@ -1047,11 +1050,11 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 			// settled here by lanes 0..17 (bwd_win_run), the nearest longer end of the longest of them being the list above
 			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0, f = 0x7fffffff;
 			unsigned long long hits = 0;
-			bool valid = lane < (uint32_t)WIN_LANES && win_lane_init(A, lane, rb, (int)bt.x, (int)bt.ret, min_intv, e, pend, s, my_q, hits, W);
+			bool valid = lane < (uint32_t)WIN_LANES && win_lane_init(A, rd, lane, (int)bt.x, (int)bt.ret, min_intv, e, pend, s, my_q, hits, W);
 			bool walking = valid;
 			while (__ballot(walking)) {
 				if (walking) {
-					uint32_t b = s < 0 ? 4u : A.seq[rb + (uint64_t)s];
+					uint32_t b = s < 0 ? 4u : rd.at(s);
 					if (b > 3) { f = s; walking = false; }
 					else {
 						Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
@@ -1068,7 +1071,7 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 			if (valid && f < fn) pushw = emit_smem(A, r, kind, e, f + 1, pend, auxw);
 			wave_push<32>(O, pushw != FTASK_NONE, pushw, A, auxw);
 		}
-		uint64_t push1 = (kind == TK_ROUND1 && lane == 0) ? chain_round1(A, r, bt.ret, bt.x) : FTASK_NONE;
+		uint64_t push1 = (kind == TK_ROUND1 && lane == 0) ? chain_round1(rd, r, (int)(A.off[r + 1] - A.off[r]), bt.ret, bt.x) : FTASK_NONE;
 		wave_push<32>(O, push1 != FTASK_NONE, push1, A);
 	}
 }
@@ -1135,17 +1138,18 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 	// walk the parked matches to their ends and report (bwd_win_run's rule, the lanes of a call found by their key)
 	auto flush = [&]() {
 		const bool mine = (int)lane < npark;
-		Intv e = {0, 0, 0}; uint32_t pend = 0, r = 0, mk = 0, key = 0, g = 0; int s = 0, f = 0x7fffffff; uint64_t rb = 0;
+		Intv e = {0, 0, 0}; uint32_t pend = 0, r = 0, mk = 0, key = 0, g = 0; int s = 0, f = 0x7fffffff;
+		PackedReader rd;
 		if (mine) {
 			const WinPark p = park[wv][lane];
 			unpack_lep(p.iv, e, pend); s = p.s; r = p.r; mk = p.mk; key = p.key; g = p.g;
-			rb = A.off[r];
+			rd.start(A.seqp, A.off[r], r, s);
 		}
 		const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
 		bool walking = mine;
 		while (__ballot(walking)) {
 			if (walking) {
-				uint32_t b = s < 0 ? 4u : (uint32_t)A.seq[rb + (uint64_t)s];
+				uint32_t b = s < 0 ? 4u : rd.at(s);
 				if (b > 3) { f = s; walking = false; }
 				else {
 					Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
@@ -1191,10 +1195,12 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 			const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
 			const uint64_t rb = job ? A.off[r] : 0;
 			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0;
-			bool alive = job && win_lane_init(A, gl, rb, x, ret, min_intv, e, pend, s, my_q, my_hits, W);
+			PackedReader rd;
+			if (job) rd.start(A.seqp, rb, r, x);
+			bool alive = job && win_lane_init(A, rd, gl, x, ret, min_intv, e, pend, s, my_q, my_hits, W);
 			for (int st = 0; st < kx; ++st) { // wave-uniform: the jump_k-mer grows to min_seed_len bases, or the lane drops out
 				if (alive) {
-					const uint32_t b = (uint32_t)A.seq[rb + (uint64_t)s];          // s >= 0: the window starts inside the read
+					const uint32_t b = rd.at(s);                                   // s >= 0: the window starts inside the read
 					if (b > 3) alive = false;
 					else {
 						Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
@@ -1209,7 +1215,7 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 			}
 			npark += __popcll(am);
 			uint64_t push1 = FTASK_NONE;
-			if (job && gl == 0 && kind == TK_ROUND1) push1 = chain_round1(A, r, ret, x);
+			if (job && gl == 0 && kind == TK_ROUND1) push1 = chain_round1(rd, r, (int)(A.off[r + 1] - rb), ret, x);
 			wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 		}
 		__builtin_amdgcn_wave_barrier();
