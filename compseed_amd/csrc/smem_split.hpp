@@ -174,101 +174,6 @@ __global__ void jump_fill_kernel(const DevIndex ix, int k, uint4 *table)
 	}
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// initial tasks: round-1 call at the first unambiguous base, and the round-3 chain (bwamem.c:226, 253)
-__global__ void init_tasks_kernel(const SplitArgs A, uint64_t *fq, uint64_t *fq_r3)
-{
-	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= A.n_reads) return;
-	uint64_t b = A.off[r]; int len = (int)(A.off[r + 1] - b), x = 0;
-	while (x < len && A.seq[b + x] > 3) ++x;
-	// the round-3 chains get a queue of their own: they depend on nothing and run on a second stream (engine.hip)
-	fq[r] = x < len ? ftask_pack((uint32_t)r, (uint32_t)x, 1, TK_ROUND1) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
-	fq_r3[r] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
-}
-
-// Task dispenser.  One returning atomic on a single word costs ~11 ns and the word saturates near 88 M dequeues/s
-// (MI355X_MICROARCH.md "dequeue"), far below the millions of short tasks per launch here, so a wave draws REFILL task
-// ids at a time with ONE atomic and hands them to its lanes with a ballot + popcount.  All state is wave-uniform.
-struct WavePool { uint64_t cur, end; bool exhausted; };
-
-template <int REFILL>
-__device__ __forceinline__ bool pool_take(WavePool &P, bool want, unsigned long long *ctr, uint64_t n_tasks, uint64_t &task)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	uint64_t m = __ballot(want);
-	if (m == 0) return false;
-	if (P.cur == P.end && !P.exhausted) {
-		int src = __ffsll((long long)m) - 1;
-		unsigned long long base = 0;
-		if ((int)lane == src) base = atomicAdd(ctr, (unsigned long long)REFILL);
-		base = __shfl(base, src);
-		if (base >= n_tasks) P.exhausted = true;
-		else { P.cur = base; P.end = base + REFILL < n_tasks ? base + REFILL : n_tasks; }
-	}
-	uint64_t avail = P.end - P.cur, cnt = (uint64_t)__popcll(m);
-	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-	task = P.cur + rank;
-	P.cur += cnt < avail ? cnt : avail;
-	return want && rank < avail;
-}
-
-// The reverse direction: a wave reserves RES slots of the next forward queue with one atomic and its lanes fill them
-// (ballot + popcount); slots left over when the wave moves on are filled with no-op tasks.
-struct WaveOut { uint64_t cur, end; };
-template <int RES>
-__device__ __forceinline__ void wave_push(WaveOut &O, bool want, uint64_t task, const SplitArgs &A, uint64_t aux = AUX_NONE)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	uint64_t m = __ballot(want);
-	if (m == 0) return;
-	uint64_t cnt = (uint64_t)__popcll(m);
-	if (O.end - O.cur < cnt) {
-		uint64_t rem = O.end - O.cur;
-		if (lane < rem) A.fq_next[O.cur + lane] = FTASK_NONE;
-		int src = __ffsll((long long)m) - 1;
-		unsigned long long base = 0;
-		if ((int)lane == src) base = atomicAdd(A.n_f_next, (unsigned long long)RES);
-		base = __shfl(base, src);
-		if (base + RES > A.fq_cap) { if ((int)lane == src) atomicMax(A.err, 2ull); O.cur = O.end = 0; return; }
-		O.cur = base; O.end = base + RES;
-	}
-	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-	if (want) { A.fq_next[O.cur + rank] = task; if (aux != AUX_NONE) A.aux_next[O.cur + rank] = aux; }
-	O.cur += cnt;
-}
-__device__ __forceinline__ void wave_push_finish(WaveOut &O, const SplitArgs &A)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	uint64_t rem = O.end - O.cur;
-	if (lane < rem) A.fq_next[O.cur + lane] = FTASK_NONE;
-	O.cur = O.end;
-}
-
-// sequential reader of a read's bases: 8-base window in a register, the next window prefetched when one is entered
-template <int DIR> struct BaseReader {
-	const uint8_t *seq; uint64_t rbase; uint64_t cur, nxt; uint64_t wk;
-	__device__ __forceinline__ void start(const uint8_t *s, uint64_t rb, int pos)
-	{
-		seq = s; rbase = rb;
-		uint64_t a = rb + (uint64_t)(pos < 0 ? 0 : pos);
-		wk = a >> 3;
-		cur = *reinterpret_cast<const uint64_t *>(seq + (wk << 3));
-		uint64_t nk = DIR > 0 ? wk + 1 : (wk ? wk - 1 : 0);
-		nxt = *reinterpret_cast<const uint64_t *>(seq + (nk << 3));
-	}
-	__device__ __forceinline__ uint32_t at(int pos)
-	{
-		uint64_t a = rbase + (uint64_t)pos, k = a >> 3;
-		if (k != wk) { // moved on by one window in direction DIR
-			cur = nxt; wk = k;
-			uint64_t nk = DIR > 0 ? k + 1 : (k ? k - 1 : 0);
-			nxt = *reinterpret_cast<const uint64_t *>(seq + (nk << 3));
-		}
-		return (uint32_t)(cur >> ((a & 7) << 3)) & 0xffu;
-	}
-};
-
 // The reads a second time, packed: one 16-byte record per 32 bases -- .x/.y the bases, 2 bits each, base j in bits 2j..2j+1 (the
 // order of the 2-bit text), .z one bit per base that is ambiguous or lies behind the end of the read.  Record k of read r is
 // rec[(off[r] >> 5) + r + k]: no second offset array, and read r owns at least len/32 + 1 records, so the record of position
@@ -371,30 +276,76 @@ __device__ __forceinline__ bool text_step(const DevIndex &ix, PackedReader &rd, 
 	return true;
 }
 
-// The jk (<= 16) read bases from byte address a on, packed 2 bits each, first base most significant (as jump_fill_kernel
-// numbers k-mers), without a per-base loop: three aligned 8-byte words, funnelled into two, each word's eight 2-bit codes
-// squeezed together by three shift-or-mask steps, then the order of the 2-bit groups reversed.  bad > 3: an ambiguous base.
-__device__ __forceinline__ uint32_t kmer_code(const uint8_t *seq, uint64_t a, int jk, uint32_t &bad)
+// ------------------------------------------------------------------------------------------------------------------
+// initial tasks: round-1 call at the first unambiguous base, and the round-3 chain (bwamem.c:226, 253)
+__global__ void init_tasks_kernel(const SplitArgs A, uint64_t *fq, uint64_t *fq_r3)
 {
-	const uint64_t a0 = a & ~7ull;
-	const uint64_t *w = reinterpret_cast<const uint64_t *>(seq + a0);
-	const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
-	const uint32_t sh = (uint32_t)(a - a0) << 3;
-	uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
-	uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
-	if (jk < 8) { lo &= (1ull << (8 * jk)) - 1ull; hi = 0; }
-	else if (jk < 16) hi &= (1ull << (8 * (jk - 8))) - 1ull;
-	bad = ((lo | hi) & 0xFCFCFCFCFCFCFCFCull) ? 4u : 0u;
-	auto squeeze = [](uint64_t v) -> uint32_t {
-		v &= 0x0303030303030303ull;
-		v = (v | (v >> 6)) & 0x000F000F000F000Full;
-		v = (v | (v >> 12)) & 0x000000FF000000FFull;
-		return (uint32_t)((v | (v >> 24)) & 0xFFFFull);
-	};
-	const uint32_t fwd = squeeze(lo) | squeeze(hi) << 16;        // base q at bits 2q
-	uint32_t rv = __brev(fwd);                                   // group q at 2(15-q), its two bits swapped
-	rv = ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
-	return rv >> (32 - 2 * jk);
+	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= A.n_reads) return;
+	uint64_t b = A.off[r]; int len = (int)(A.off[r + 1] - b), x = 0;
+	PackedReader rd; rd.start(A.seqp, b, (uint32_t)r, 0);
+	while (x < len && rd.at(x) > 3) ++x;
+	// the round-3 chains get a queue of their own: they depend on nothing and run on a second stream (engine.hip)
+	fq[r] = x < len ? ftask_pack((uint32_t)r, (uint32_t)x, 1, TK_ROUND1) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+	fq_r3[r] = (len > 0 && A.max_mem_intv > 0) ? ftask_pack((uint32_t)r, 0, 0, TK_ROUND3) : ftask_pack((uint32_t)r, 0, 0, TK_NOP);
+}
+
+// Task dispenser.  One returning atomic on a single word costs ~11 ns and the word saturates near 88 M dequeues/s
+// (MI355X_MICROARCH.md "dequeue"), far below the millions of short tasks per launch here, so a wave draws REFILL task
+// ids at a time with ONE atomic and hands them to its lanes with a ballot + popcount.  All state is wave-uniform.
+struct WavePool { uint64_t cur, end; bool exhausted; };
+
+template <int REFILL>
+__device__ __forceinline__ bool pool_take(WavePool &P, bool want, unsigned long long *ctr, uint64_t n_tasks, uint64_t &task)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t m = __ballot(want);
+	if (m == 0) return false;
+	if (P.cur == P.end && !P.exhausted) {
+		int src = __ffsll((long long)m) - 1;
+		unsigned long long base = 0;
+		if ((int)lane == src) base = atomicAdd(ctr, (unsigned long long)REFILL);
+		base = __shfl(base, src);
+		if (base >= n_tasks) P.exhausted = true;
+		else { P.cur = base; P.end = base + REFILL < n_tasks ? base + REFILL : n_tasks; }
+	}
+	uint64_t avail = P.end - P.cur, cnt = (uint64_t)__popcll(m);
+	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+	task = P.cur + rank;
+	P.cur += cnt < avail ? cnt : avail;
+	return want && rank < avail;
+}
+
+// The reverse direction: a wave reserves RES slots of the next forward queue with one atomic and its lanes fill them
+// (ballot + popcount); slots left over when the wave moves on are filled with no-op tasks.
+struct WaveOut { uint64_t cur, end; };
+template <int RES>
+__device__ __forceinline__ void wave_push(WaveOut &O, bool want, uint64_t task, const SplitArgs &A, uint64_t aux = AUX_NONE)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t m = __ballot(want);
+	if (m == 0) return;
+	uint64_t cnt = (uint64_t)__popcll(m);
+	if (O.end - O.cur < cnt) {
+		uint64_t rem = O.end - O.cur;
+		if (lane < rem) A.fq_next[O.cur + lane] = FTASK_NONE;
+		int src = __ffsll((long long)m) - 1;
+		unsigned long long base = 0;
+		if ((int)lane == src) base = atomicAdd(A.n_f_next, (unsigned long long)RES);
+		base = __shfl(base, src);
+		if (base + RES > A.fq_cap) { if ((int)lane == src) atomicMax(A.err, 2ull); O.cur = O.end = 0; return; }
+		O.cur = base; O.end = base + RES;
+	}
+	uint64_t rank = (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+	if (want) { A.fq_next[O.cur + rank] = task; if (aux != AUX_NONE) A.aux_next[O.cur + rank] = aux; }
+	O.cur += cnt;
+}
+__device__ __forceinline__ void wave_push_finish(WaveOut &O, const SplitArgs &A)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint64_t rem = O.end - O.cur;
+	if (lane < rem) A.fq_next[O.cur + lane] = FTASK_NONE;
+	O.cur = O.end;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -420,42 +371,11 @@ __global__ void kmer_filter_fill_kernel(const DevIndex ix, int k, uint64_t *bloo
 		atomicOr((unsigned long long *)&bloom[h >> (64u - bits)], (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)));
 	}
 }
-// the k (<= 24) read bases from byte address a on as a filter code; bad > 3: an ambiguous base among them
-__device__ __forceinline__ uint64_t kmer_code_lsb(const uint8_t *seq, uint64_t a, int k, uint32_t &bad)
-{
-	const uint64_t a0 = a & ~7ull;
-	const uint64_t *w = reinterpret_cast<const uint64_t *>(seq + a0);
-	const uint64_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-	const uint32_t sh = (uint32_t)(a - a0) << 3;
-	uint64_t b0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;      // bases 0..7
-	uint64_t b1 = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;      // bases 8..15
-	uint64_t b2 = sh ? (w2 >> sh) | (w3 << (64u - sh)) : w2;      // bases 16..23
-	if (k < 24) b2 &= k > 16 ? ((1ull << (8 * (k - 16))) - 1ull) : 0ull;
-	if (k < 16) b1 &= k > 8 ? ((1ull << (8 * (k - 8))) - 1ull) : 0ull;
-	if (k < 8) b0 &= (1ull << (8 * k)) - 1ull;
-	bad = ((b0 | b1 | b2) & 0xFCFCFCFCFCFCFCFCull) ? 4u : 0u;
-	auto squeeze = [](uint64_t v) -> uint64_t {
-		v &= 0x0303030303030303ull;
-		v = (v | (v >> 6)) & 0x000F000F000F000Full;
-		v = (v | (v >> 12)) & 0x000000FF000000FFull;
-		return (v | (v >> 24)) & 0xFFFFull;
-	};
-	return squeeze(b0) | squeeze(b1) << 16 | squeeze(b2) << 32;
-}
-
 // the call that follows a finished round-1 call at pivot x_cur: next pivot = end of the longest forward match, ambiguous
 // bases skipped.  A round-1 task carries, in the field that holds min_intv for round 2 (round 1 always uses 1), the
 // distance to the previous pivot + 1 when the forward pass ended ON the new pivot (no ambiguous base in between): no
 // match that starts at or before the previous pivot reaches beyond the new one, which bounds the new call's sweep.
-__device__ __forceinline__ uint64_t chain_round1(const SplitArgs &A, uint32_t r, int ret, int x_cur)
-{
-	uint64_t rb = A.off[r]; int len = (int)(A.off[r + 1] - rb), x = ret;
-	while (x < len && A.seq[rb + x] > 3) ++x;
-	uint32_t d = (x == ret && ret - x_cur < 16382) ? (uint32_t)(ret - x_cur) : 0u;
-	return x < len ? ftask_pack(r, (uint32_t)x, 1u + d, TK_ROUND1) : FTASK_NONE;
-}
-
-__device__ __forceinline__ uint64_t chain_round1(PackedReader &rd, uint32_t r, int len, int ret, int x_cur) // the same over the packed read
+__device__ __forceinline__ uint64_t chain_round1(PackedReader &rd, uint32_t r, int len, int ret, int x_cur)
 {
 	int x = ret;
 	while (x < len && rd.at(x) > 3) ++x;
@@ -738,7 +658,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 	uint32_t r = 0, kind = 0, min_intv = 1, pend = 0;
 	int i = 0, ret = 0, nm = 0, last_start = 0, xp = 0;
 	Intv e = {0, 0, 0};
-	BaseReader<-1> rd;
+	PackedReader rd;
 
 	// Every lane of the wave stays in the loop until the whole wave is done, and every lane executes the dispenser code at
 	// the top and the bottom of each iteration, so its wave-uniform state stays identical in all lanes.
@@ -780,12 +700,12 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				live = (int)gl < n;
 				if (live) { unpack_lep(A.lep[(size_t)t * A.lep_stride + (n - 1 - (int)gl)], e, pend); wc_add(W, EV_LEP); }
 				uint64_t rb = A.off[r];
-				rd.start(A.seq, rb, x - 1);
+				rd.start(A.seqp, rb, r, x - 1);
 				i = x - 1; nm = 0; last_start = 0;
 				slen = SST2_K; scode = 0;
 				if (use_sst && live && (int)pend - x < SST2_K) { // a short LEP: spell it, the SST is keyed by the string
 					slen = (int)pend - x;
-					for (int q = 0; q < slen; ++q) scode = scode << 2 | A.seq[rb + x + q];
+					for (int q = 0; q < slen; ++q) scode = scode << 2 | rd.at(x + q);
 				}
 				active = true;
 			}
@@ -828,7 +748,7 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 				if (cand_m == 0) end_call = true; else --i; // the first surviving match is always kept
 			}
 			if (end_call) {
-				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(A, r, ret, xp);
+				if (kind == TK_ROUND1 && gl == 0) push1 = chain_round1(rd, r, (int)(A.off[r + 1] - A.off[r]), ret, xp);
 				active = false;
 			}
 		}
@@ -1287,7 +1207,7 @@ __device__ __forceinline__ void lc_flush(LaneCtr c, WaveCtr &W)
 {
 	W.addn(EV_SA, c.sa); W.addn(EV_ISA, c.isa); W.addn(EV_REP, c.rep); W.addn(EV_LCP, c.lcp); W.addn(EV_MEM, c.mem);
 }
-struct RepReader { // rep[] bytes around a moving text position, one aligned 8-byte load per 8 positions
+struct RepReader { // rep[] / lcp[] bytes around a moving position, one aligned 8-byte load per 8 positions (the arrays are padded)
 	const uint8_t *base; uint64_t wk, w; uint32_t loads;
 	__device__ __forceinline__ uint32_t at(uint64_t pos)
 	{
@@ -1296,16 +1216,30 @@ struct RepReader { // rep[] bytes around a moving text position, one aligned 8-b
 		return (uint32_t)(w >> ((pos & 7) << 3)) & 0xffu;
 	}
 };
+#ifndef CS_LCP_BYTES
+#define CS_LCP_BYTES 0
+#endif
+#if CS_LCP_BYTES
+struct LcpReader { // (A/B variant: one byte per load, as before)
+	static constexpr uint32_t BYTES = 1;
+	const uint8_t *base; uint64_t wk, w; uint32_t loads;
+	__device__ __forceinline__ uint32_t at(uint64_t pos) { ++loads; return base[pos]; }
+};
+#else
+struct LcpReader : RepReader { static constexpr uint32_t BYTES = 8; };
+#endif
 // bi-interval of the repeated substring of length v at text position pos (v <= 254, so the capped lcp[] decides exactly)
 __device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, uint32_t v, Intv &out, LaneCtr &C, int MAX_WALK = 48)
 {
 	if (v == 0 || pos + v > ix.seq_len) return false; // (cannot happen for a substring of a mem; a walk must never leave the arrays)
 	uint64_t lo = isa_direct(ix, pos), hi = lo, lo2 = isa_direct(ix, ix.seq_len - (pos + v));
 	int steps = 0;
-	C.isa += 2; C.lcp += 3;
-	while (lo > 0 && ix.lcp[lo] >= v) { --lo; ++C.lcp; if (++steps > MAX_WALK) return false; }
-	while (hi < ix.seq_len && ix.lcp[hi + 1] >= v) { ++hi; ++C.lcp; if (++steps > MAX_WALK) return false; }
-	while (lo2 > 0 && ix.lcp[lo2] >= v) { --lo2; ++C.lcp; if (++steps > 2 * MAX_WALK) return false; }
+	C.isa += 2;
+	LcpReader Lr = {ix.lcp, ~0ull, 0, 0}; // a walk is a chain of dependent loads: eight rows per load instead of one
+	struct Tally { LcpReader &R; LaneCtr &C; __device__ ~Tally() { C.lcp += LcpReader::BYTES * R.loads; } } tally = {Lr, C};
+	while (lo > 0 && Lr.at(lo) >= v) { --lo; if (++steps > MAX_WALK) return false; }
+	while (hi < ix.seq_len && Lr.at(hi + 1) >= v) { ++hi; if (++steps > MAX_WALK) return false; }
+	while (lo2 > 0 && Lr.at(lo2) >= v) { --lo2; if (++steps > 2 * MAX_WALK) return false; }
 	out.x0 = lo; out.x1 = lo2; out.x2 = hi - lo + 1;
 	return true;
 }
@@ -1416,14 +1350,15 @@ __device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int 
 	const uint32_t m = max_intv - 1;
 	if (p >= ix.seq_len) return false;
 	uint64_t up = isa_direct(ix, p), dn = up + 1;
-	uint32_t mu = ix.lcp[up], md = ix.lcp[dn], val = 0;
-	++C.isa; C.lcp += 2;
+	LcpReader Lu = {ix.lcp, ~0ull, 0, 0}, Ld = {ix.lcp, ~0ull, 0, 0}; // one window per side: ~3 dependent loads instead of up to 19
+	struct Tally { LcpReader &A, &B; LaneCtr &C; __device__ ~Tally() { C.lcp += LcpReader::BYTES * (A.loads + B.loads); } } tally = {Lu, Ld, C};
+	uint32_t mu = Lu.at(up), md = Ld.at(dn), val = 0;
+	++C.isa;
 	for (uint32_t t = 0; t < m; ++t) {
 		val = mu > md ? mu : md;
 		if (val < (uint32_t)k1) { L = k1; return true; }   // fewer than max_intv occurrences already at k1 bases
-		++C.lcp;
-		if (mu >= md) { if (up == 0) return false; --up; const uint32_t c = ix.lcp[up]; mu = c < mu ? c : mu; }
-		else { if (dn > ix.seq_len) return false; ++dn; const uint32_t c = ix.lcp[dn]; md = c < md ? c : md; }
+		if (mu >= md) { if (up == 0) return false; --up; const uint32_t c = Lu.at(up); mu = c < mu ? c : mu; }
+		else { if (dn > ix.seq_len) return false; ++dn; const uint32_t c = Ld.at(dn); md = c < md ? c : md; }
 	}
 	if (val >= 255u) return false;                          // the true shared length is not known
 	L = (int)val + 1;
@@ -1433,7 +1368,10 @@ __device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int 
 // cnt_snap: the per-read mem counts at a moment when every entry below them was complete (a copy taken between launches):
 // the kernel may run beside the last, thin iterations of rounds 1/2, which keep appending to the same lists.  A read that is
 // still being worked on simply finds fewer covering mems and takes more of its seeds from the index.
-__global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const uint32_t *cnt_snap, unsigned long long *n_text_seeds)
+#ifndef CS_R3_WAVES
+#define CS_R3_WAVES 5
+#endif
+__global__ __launch_bounds__(256, CS_R3_WAVES) void r3text_kernel(const SplitArgs A, const uint32_t *cnt_snap, unsigned long long *n_text_seeds)
 {
 	const DevIndex &ix = A.ix;
 	const int k1 = A.min_seed_len + 1;
@@ -1447,8 +1385,9 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 		const OutMem *mine = A.out + (size_t)r * A.cap;
 		int cb = 0, ce = 0; uint64_t cp = 0; // the mem the cursor is in: [cb, ce) at text position cp
 		int x = 0;
+		PackedReader rd; rd.start(A.seqp, rb, (uint32_t)r, 0);
 		while (x < len) {
-			if (A.seq[rb + (uint64_t)x] > 3) { ++x; continue; }
+			if (rd.at(x) > 3) { ++x; continue; }
 			if (!(x >= cb && x + k1 <= ce)) { // look for a mem that covers [x, x + k1)
 				cb = ce = 0;
 				for (uint32_t a = 0; a < nm0; ++a) {
@@ -1518,14 +1457,11 @@ __global__ __launch_bounds__(256) void r3text_kernel(const SplitArgs A, const ui
 			// bwt_seed_strategy1 on the index
 			Intv ik; int i; bool jumped = false;
 			if (jk && x + jk <= len) {
-				uint32_t code = 0, bad = 0;
-				for (int q = 0; q < jk; ++q) { uint32_t b = A.seq[rb + (uint64_t)(x + q)]; bad |= b; code = code << 2 | (b & 3u); }
+				uint32_t bad; const uint32_t code = rd.kmer(x, jk, bad);
 				if (bad <= 3) { uint32_t dummy; unpack_lep(A.jump[code], ik, dummy); wc_add(W, EV_JUMP); i = x + jk; jumped = true; my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1); }
 			}
-			if (!jumped) { ik = set_intv(ix, (int)A.seq[rb + (uint64_t)x]); i = x + 1; }
+			if (!jumped) { ik = set_intv(ix, (int)rd.at(x)); i = x + 1; }
 			int nx = len;
-			BaseReader<1> rd;          // 8 read bases per load, the next 8 prefetched: in repeats a seed is a chain of dozens of steps
-			rd.start(A.seq, rb, i);
 			bool dead = ik.x2 == 0; // an empty interval stays empty (bwt.c:369 keeps extending it): no more index reads, the
 			                        // reference still walks on to the first ambiguous base or to min_seed_len bases and reports nothing
 			for (; i < len; ++i) {
