@@ -1255,12 +1255,17 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 	const uint64_t P = sa_direct(ix, x0); // text position of read base `beg`
 	++C.sa;
 	if (P >= ix.seq_len || P + (uint64_t)len > ix.seq_len) return false; // (an SMEM lies inside the text)
-	RepReader R = {ix.rep, ~0ull, 0, 0};
-	struct Tally { RepReader &R; LaneCtr &C; __device__ ~Tally() { C.rep += R.loads; } } tally = {R, C};
+	// rep[] of the SMEM's bases, eight per aligned load; the window covers the offsets [wo, wo + 8) of the SMEM (32-bit arithmetic:
+	// the walk is this kernel's inner loop, and a wave runs as long as its longest walk)
+	const uint8_t *rp = ix.rep + P;
+	int wo = po - (int)((P + (uint64_t)po) & 7ull);
+	uint64_t w = *reinterpret_cast<const uint64_t *>(rp + wo);
+	uint32_t loads = 1;
+	struct Tally { uint32_t &n; LaneCtr &C; __device__ ~Tally() { C.rep += n; } } tally = {loads, C};
 	constexpr int MAXC = 8;               // reported substrings per call; more (tandem arrays): leave it to the index
 	int co[MAXC], cv[MAXC], ne = 0;
-	auto eff = [&](int o, int &v) -> bool { // repeat length at offset o as far as it matters; false: the text cannot tell
-		v = (int)R.at(P + (uint64_t)o);
+	auto eff = [&](int o, int &v) -> bool { // repeat length at offset o (inside the window) as far as it matters; false: the text cannot tell
+		v = (int)((uint32_t)(w >> ((uint32_t)(o - wo) << 3)) & 0xffu);
 		if (v == 0) return false;
 		if (o + v >= len) { if (!at_end) return false; v = len - o; return true; } // (a capped 255 that reaches the end is as good as the true value)
 		return v != 255;
@@ -1274,6 +1279,7 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 			if (v >= k) { if (ne == MAXC) return false; co[ne] = 0; cv[ne] = v; ++ne; }
 			break;
 		}
+		if (o == wo) { wo -= 8; w = *reinterpret_cast<const uint64_t *>(rp + wo); ++loads; } // (P + wo >= 0: an aligned address below P + o)
 		int vp = 0;
 		if (!eff(o - 1, vp)) return false;
 		if (vp <= v && v >= k) { if (ne == MAXC) return false; co[ne] = o; cv[ne] = v; ++ne; }
@@ -1286,7 +1292,10 @@ __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint6
 }
 // One lane per slot of the next forward queue.  Calls that are answered drop out; everything else is copied, without the
 // no-op padding, to `fq_out` (the queue the finished iteration has consumed), so the next launches see a dense queue.
-__global__ __launch_bounds__(256) void r2text_kernel(const SplitArgs A, const uint64_t *fq, const uint64_t *aux, const unsigned long long *n_ptr,
+#ifndef CS_R2_WAVES
+#define CS_R2_WAVES 6
+#endif
+__global__ __launch_bounds__(256, CS_R2_WAVES) void r2text_kernel(const SplitArgs A, const uint64_t *fq, const uint64_t *aux, const unsigned long long *n_ptr,
                                                      unsigned long long *n_done, unsigned long long *n_left, uint64_t *fq_out, unsigned long long *n_out)
 {
 	uint64_t n = *n_ptr; if (n > A.fq_cap) n = A.fq_cap;
@@ -1454,7 +1463,17 @@ __global__ __launch_bounds__(256, CS_R3_WAVES) void r3text_kernel(const SplitArg
 					continue;
 				}
 			}
-			// bwt_seed_strategy1 on the index
+			// bwt_seed_strategy1 on the index -- unless the min_seed_len-mer at x does not occur at all (the filter of the window
+			// scheme; typically a seed across a mismatch): then the interval runs empty before the seed may end, the reference walks on
+			// to min_seed_len + 1 bases reporting nothing (bwt.c:369-371), and the next seed starts there
+			if (A.bloom && x + A.min_seed_len <= len) {
+				uint32_t badw; const uint64_t w = rd.window(x, A.min_seed_len, badw); wc_add(W, EV_BLOOM);
+				if (!(badw & ((1u << A.min_seed_len) - 1u)) && !kmer_filter_has(A.bloom, A.bloom_bits, w & ((1ull << (2 * A.min_seed_len)) - 1ull))) {
+					my_q += (unsigned)(A.min_seed_len - 1); my_hits += (unsigned)(A.min_seed_len - 1);
+					x = x + k1 < len ? x + k1 : len;
+					continue;
+				}
+			}
 			Intv ik; int i; bool jumped = false;
 			if (jk && x + jk <= len) {
 				uint32_t bad; const uint32_t code = rd.kmer(x, jk, bad);
