@@ -778,9 +778,9 @@ __device__ __forceinline__ void bwd_groups_run(const SplitArgs &A, const BTask *
 // replace 136 extensions, 17 deep; results identical.
 //
 // A group of G lanes per call: lanes 0..17 take the ends x+1 .. x+18, lanes 18.. take the stored LEPs in ascending order.
+// in two halves: the filter (does the end's min_seed_len-mer occur at all? -> its jump-table code), and the table lookup
 template <class WC>
-__device__ __forceinline__ bool win_lane_init(const SplitArgs &A, PackedReader &rd, uint32_t gl, int x, int ret, uint32_t min_intv,
-                                              Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits, WC &W)
+__device__ __forceinline__ bool win_lane_filter(const SplitArgs &A, PackedReader &rd, uint32_t gl, int x, int ret, uint32_t &code, WC &W)
 {
 	const int k = A.min_seed_len, jk = A.jump_k; // jk <= k <= 24 (the window scheme's range)
 	const int te = x + 1 + (int)gl;
@@ -792,13 +792,27 @@ __device__ __forceinline__ bool win_lane_init(const SplitArgs &A, PackedReader &
 		wc_add(W, EV_BLOOM);
 		if (!kmer_filter_has(A.bloom, A.bloom_bits, w & ((1ull << (2 * k)) - 1ull))) return false;
 	}
-	uint32_t code = __brev((uint32_t)(w >> (2 * (k - jk))));       // group q at 2(15-q), its two bits swapped
+	code = __brev((uint32_t)(w >> (2 * (k - jk))));                // group q at 2(15-q), its two bits swapped
 	code = (((code & 0xAAAAAAAAu) >> 1) | ((code & 0x55555555u) << 1)) >> (32 - 2 * jk);
+	return true;
+}
+template <class WC>
+__device__ __forceinline__ bool win_lane_jump(const SplitArgs &A, uint32_t code, int te, uint32_t min_intv,
+                                              Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits, WC &W)
+{
+	const int jk = A.jump_k;
 	uint32_t dummy; unpack_lep(A.jump[code], e, dummy); wc_add(W, EV_JUMP);
 	my_q += (unsigned)(jk - 1); my_hits += (unsigned)(jk - 1);
 	if (e.x2 < min_intv) return false;
 	pend = (uint32_t)te; s = te - jk - 1;
 	return true;
+}
+template <class WC>
+__device__ __forceinline__ bool win_lane_init(const SplitArgs &A, PackedReader &rd, uint32_t gl, int x, int ret, uint32_t min_intv,
+                                              Intv &e, uint32_t &pend, int &s, unsigned long long &my_q, unsigned long long &my_hits, WC &W)
+{
+	uint32_t code;
+	return win_lane_filter(A, rd, gl, x, ret, code, W) && win_lane_jump(A, code, x + 1 + (int)gl, min_intv, e, pend, s, my_q, my_hits, W);
 }
 
 template <int G, class WC>
@@ -1030,20 +1044,24 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 }
 
 // Calls without any stored LEP (the forward match is shorter than min_seed_len: typically the call at a mismatch, whose
-// matches are all chance matches) are the bulk, and all their work is the 18 window lookups, of which 98 % die within
-// four extensions.  They get a kernel of their own that packs three calls into a wave (54 of 64 lanes busy) instead of
-// one call per 32-lane group: a wave owns 64 consecutive slots, finds this class by ballot and works through it three
-// at a time.  Each round is the jump-table read plus exactly min_seed_len - jump_k extensions in lockstep; the few
-// lanes that still match after that are PARKED in LDS, and only when enough of them have gathered (or the 64 slots are
-// done) does the wave walk them on to their ends, all together, and apply the first-survivor rule per call.  (Walking
-// them inside their round kept the whole wave waiting for one or two lanes a third of the time; the kernel is VALU-bound.)
+// matches are all chance matches) are the bulk, and all their work is the 18 window lookups, of which 97 % end at the
+// filter.  They get a kernel of their own that packs three calls into a wave (54 of 64 lanes busy) instead of one call per
+// 32-lane group: a wave owns 64 consecutive slots, finds this class by ballot and works through it three at a time.  A round
+// is the filter alone; the ends that pass it are PARKED in LDS (16 bytes: read, end, jump-table code, call key), and only
+// when 64 of them have gathered does the wave look them up in the jump table, extend them to min_seed_len in lockstep,
+// walk the survivors on to their ends -- all of that on full waves instead of one or two lanes out of 64 -- and apply the
+// first-survivor rule per call (the lanes of a call found by their key).  The kernel is VALU-bound: that is the point.
 // No dispenser and no atomics on the task side.
-struct WinPark { uint4 iv; int32_t s; uint32_t r; uint16_t mk; uint8_t key, g; uint32_t pad; }; // 32 B: a match that reached min_seed_len
+struct WinPark { uint32_t r, code; int32_t te; uint16_t mk, key; };             // an end that passed the filter; key: 64-slot batch (10 bits) | slot (6)
+#ifndef CS_WIN0_WAVES
+#define CS_WIN0_WAVES 6
+#endif
 template <int BLOCK, bool COUNT>
-__global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
+__global__ __launch_bounds__(BLOCK, CS_WIN0_WAVES) void bwd_win0_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks)
 {
 	if (*A.n_btasks == 0) return;
 	constexpr int PARK = 64;
+	constexpr int32_t F_DEAD = (int32_t)0x80000000;
 	__shared__ uint8_t rank2lane[BLOCK / 64][64];
 	__shared__ WinPark park[BLOCK / 64][PARK];
 	__shared__ int32_t park_f[BLOCK / 64][PARK];
@@ -1054,19 +1072,31 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 	WaveOut O = {0, 0};
 	WaveCtrT<COUNT> W;
 	unsigned long long my_q = 0, my_hits = 0;
-	int npark = 0; // wave-uniform
-	// walk the parked matches to their ends and report (bwd_win_run's rule, the lanes of a call found by their key)
+	int npark = 0; uint32_t park_seq0 = 0; // wave-uniform: parked ends, batch number of the oldest of them
 	auto flush = [&]() {
+		__builtin_amdgcn_wave_barrier();
 		const bool mine = (int)lane < npark;
-		Intv e = {0, 0, 0}; uint32_t pend = 0, r = 0, mk = 0, key = 0, g = 0; int s = 0, f = 0x7fffffff;
+		Intv e = {0, 0, 0}; uint32_t pend = 0, r = 0, mk = 0, key = 0; int s = 0, f = 0x7fffffff, te = 0;
 		PackedReader rd;
+		bool alive = false;
 		if (mine) {
 			const WinPark p = park[wv][lane];
-			unpack_lep(p.iv, e, pend); s = p.s; r = p.r; mk = p.mk; key = p.key; g = p.g;
-			rd.start(A.seqp, A.off[r], r, s);
+			r = p.r; mk = p.mk; key = p.key; te = p.te;
+			alive = win_lane_jump(A, p.code, te, mk & 0x3fffu, e, pend, s, my_q, my_hits, W);
+			if (alive) rd.start(A.seqp, A.off[r], r, s);
 		}
 		const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
-		bool walking = mine;
+		for (int st = 0; st < kx; ++st) { // wave-uniform: the jump_k-mer grows to min_seed_len bases, or the lane drops out
+			if (alive) {
+				const uint32_t b = rd.at(s);                                   // s >= 0: the window starts inside the read
+				if (b > 3) alive = false;
+				else {
+					Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
+					if (y.x2 < min_intv) alive = false; else { e = y; --s; }
+				}
+			}
+		}
+		bool walking = alive;
 		while (__ballot(walking)) {
 			if (walking) {
 				uint32_t b = s < 0 ? 4u : rd.at(s);
@@ -1077,16 +1107,16 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 				}
 			}
 		}
-		if (mine) park_f[wv][lane] = f;
+		if (mine) park_f[wv][lane] = alive ? f : F_DEAD;
 		__builtin_amdgcn_wave_barrier();
-		bool emit = mine;
-		if (mine) { // the nearest longer match of the same call among the parked ones
-			uint32_t best_g = 256; int best_f = 0;
+		bool emit = alive;
+		if (alive) { // the nearest longer match of the same call among the parked ones that reached min_seed_len
+			int best_te = 0x7fffffff, best_f = 0;
 			for (int q = 0; q < npark; ++q) {
-				const uint32_t kq = park[wv][q].key, gq = park[wv][q].g;
-				if (kq == key && gq > g && gq < best_g) { best_g = gq; best_f = park_f[wv][q]; }
+				const int tq = park[wv][q].te, fq2 = park_f[wv][q];
+				if (park[wv][q].key == key && fq2 != F_DEAD && tq > te && tq < best_te) { best_te = tq; best_f = fq2; }
 			}
-			emit = best_g == 256 || f < best_f;
+			emit = best_te == 0x7fffffff || f < best_f;
 		}
 		uint64_t push0 = FTASK_NONE, aux0 = AUX_NONE;
 		if (emit) push0 = emit_smem(A, r, kind, e, f + 1, pend, aux0);
@@ -1095,7 +1125,8 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 		npark = 0;
 	};
 	const uint64_t n_batches = (n_tasks + 63) / 64, wstride = (uint64_t)gridDim.x * (BLOCK / 64);
-	for (uint64_t bch = (uint64_t)blockIdx.x * (BLOCK / 64) + wv; bch < n_batches; bch += wstride) { // wave-uniform
+	uint32_t bseq = 0;
+	for (uint64_t bch = (uint64_t)blockIdx.x * (BLOCK / 64) + wv; bch < n_batches; bch += wstride, ++bseq) { // wave-uniform
 		const uint64_t slot = bch * 64 + lane;
 		BTask bt = {0, 0, 0, 0, 0, 0xffffffffu};
 		if (slot < n_tasks) bt = bq[slot];
@@ -1103,34 +1134,26 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 		const uint64_t m = __ballot(is);
 		const int cnt = __popcll(m);
 		if (cnt == 0) continue;
+		if (npark && bseq - park_seq0 >= 1000u) flush(); // (keys carry ten bits of the batch number)
 		if (is) rank2lane[wv][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
 		__builtin_amdgcn_wave_barrier();
 		for (int r0 = 0; r0 < cnt; r0 += 3) { // wave-uniform
-			if (npark > PARK - 3 * WIN_LANES) flush();
 			const int rank = r0 + (int)seg;
 			const bool job = seg < 3 && rank < cnt;
 			const int src = job ? (int)rank2lane[wv][rank] : (int)lane;
 			const uint32_t r = __shfl(bt.r, src), mk = __shfl((uint32_t)bt.mi_kind, src);
 			const int x = __shfl((int)bt.x, src), ret = __shfl((int)bt.ret, src);
-			const uint32_t kind = mk >> 14, min_intv = mk & 0x3fffu;
+			const uint32_t kind = mk >> 14;
 			const uint64_t rb = job ? A.off[r] : 0;
-			Intv e = {0, 0, 0}; uint32_t pend = 0; int s = 0;
 			PackedReader rd;
 			if (job) rd.start(A.seqp, rb, r, x);
-			bool alive = job && win_lane_init(A, rd, gl, x, ret, min_intv, e, pend, s, my_q, my_hits, W);
-			for (int st = 0; st < kx; ++st) { // wave-uniform: the jump_k-mer grows to min_seed_len bases, or the lane drops out
-				if (alive) {
-					const uint32_t b = rd.at(s);                                   // s >= 0: the window starts inside the read
-					if (b > 3) alive = false;
-					else {
-						Intv y = extend1<true>(ix, e, (int)b, W); ++my_q;
-						if (y.x2 < min_intv) alive = false; else { e = y; --s; }
-					}
-				}
-			}
-			const uint64_t am = __ballot(alive);
-			if (alive) {
-				WinPark p; p.iv = pack_lep(e, pend); p.s = s; p.r = r; p.mk = (uint16_t)mk; p.key = (uint8_t)src; p.g = (uint8_t)gl; p.pad = 0;
+			uint32_t code = 0;
+			const bool pass = job && win_lane_filter(A, rd, gl, x, ret, code, W);
+			const uint64_t am = __ballot(pass);
+			if (npark + __popcll(am) > PARK) flush();
+			if (npark == 0) park_seq0 = bseq;
+			if (pass) {
+				WinPark p; p.r = r; p.code = code; p.te = x + 1 + (int)gl; p.mk = (uint16_t)mk; p.key = (uint16_t)((bseq & 0x3ffu) << 6 | (uint32_t)src);
 				park[wv][npark + __popcll(am & ((1ull << lane) - 1ull))] = p;
 			}
 			npark += __popcll(am);
@@ -1139,9 +1162,8 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win0_kernel(const SplitArgs A, c
 			wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 		}
 		__builtin_amdgcn_wave_barrier();
-		// the parked matches of different 64-slot batches may share a key: settle them before the keys are reused
-		if (npark) flush();
 	}
+	if (npark) flush();
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, my_hits);
