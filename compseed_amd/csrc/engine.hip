@@ -797,9 +797,9 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				// side streams: the calls with more than 46 / 64 LEPs, one wave each (few on a mostly unique genome, many on a repeat-rich one:
 				// four blocks per CU so that they overlap their list reads), and the calls without stored LEPs (the bulk of the calls)
 				HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
-				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
+				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * CS_WIDE_BLOCKS, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
 				                              (const BTask *)e->d_bq.p, cn, C + 5);
-				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 4, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
+				else hipLaunchKernelGGL(bwd_wide_kernel<false>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * CS_WIDE_BLOCKS, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
 				                        (const BTask *)e->d_bq.p, cn, C + 5);
 				HIP_TRY(hipEventRecord(e->ev_wc, e->stream4));
 				if (A.win)

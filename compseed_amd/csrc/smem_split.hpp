@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(BLOCK, CS_WIN0_WAVES) void bwd_win0_kernel(const Sp
 		npark = 0;
 	};
 	const uint64_t n_batches = (n_tasks + 63) / 64, wstride = (uint64_t)gridDim.x * (BLOCK / 64);
+	const int k = A.min_seed_len, jk = A.jump_k;
 	uint32_t bseq = 0;
 	for (uint64_t bch = (uint64_t)blockIdx.x * (BLOCK / 64) + wv; bch < n_batches; bch += wstride, ++bseq) { // wave-uniform
 		const uint64_t slot = bch * 64 + lane;
@@ -1135,7 +1136,28 @@ __global__ __launch_bounds__(BLOCK, CS_WIN0_WAVES) void bwd_win0_kernel(const Sp
 		const int cnt = __popcll(m);
 		if (cnt == 0) continue;
 		if (npark && bseq - park_seq0 >= 1000u) flush(); // (keys carry ten bits of the batch number)
-		if (is) rank2lane[wv][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+		// Per slot, all calls of the batch at once: the bases every window of the call can touch, [x + 1 - k, x + 18), as one
+		// 96-bit string + ambiguity bits (three records at most), and the call's successor.  The rounds below then need no
+		// memory access but the filter word itself.
+		uint64_t cw0 = 0, cbad = ~0ull; uint32_t cw1 = 0; uint64_t push1 = FTASK_NONE;
+		if (is) {
+			const uint64_t rb = A.off[bt.r]; const int len = (int)(A.off[bt.r + 1] - rb);
+			PackedReader rd; rd.rec = A.seqp + (rb >> 5) + bt.r;
+			const int c0 = (int)bt.x + 1 - k, start = c0 < 0 ? 0 : c0;
+			const uint32_t sh = (uint32_t)(start - c0), j0 = (uint32_t)start & 31u;
+			const int i0 = start >> 5, imax = len >> 5;           // (record imax exists and ends the read)
+			const uint4 none = {0u, 0u, ~0u, 0u};
+			const uint4 q0 = rd.rec[i0], q1 = i0 + 1 <= imax ? rd.rec[i0 + 1] : none, q2 = i0 + 2 <= imax ? rd.rec[i0 + 2] : none;
+			const uint64_t b0 = (uint64_t)q0.x | (uint64_t)q0.y << 32, b1 = (uint64_t)q1.x | (uint64_t)q1.y << 32, b2 = (uint64_t)q2.x | (uint64_t)q2.y << 32;
+			uint64_t wa = b0 >> (j0 << 1), wb = b1 >> (j0 << 1);      // bases start .. start+31 and start+32 .. start+63
+			uint64_t bad = ((uint64_t)q1.z << 32 | q0.z) >> j0;         // their ambiguity bits (64 - j0 of them; the rest from q2)
+			if (j0) { wa |= b1 << ((32u - j0) << 1); wb |= b2 << ((32u - j0) << 1); bad |= (uint64_t)q2.z << (64u - j0); }
+			if (sh) { wb = wb << (sh << 1) | wa >> (64u - (sh << 1)); wa <<= sh << 1; bad = bad << sh | ((1ull << sh) - 1ull); } // the read starts inside the range
+			cw0 = wa; cw1 = (uint32_t)wb; cbad = bad;
+			if ((bt.mi_kind >> 14) == TK_ROUND1) { rd.wk = i0; rd.bases = b0; rd.bad = q0.z; push1 = chain_round1(rd, bt.r, len, (int)bt.ret, (int)bt.x); }
+			rank2lane[wv][__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+		}
+		wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 		__builtin_amdgcn_wave_barrier();
 		for (int r0 = 0; r0 < cnt; r0 += 3) { // wave-uniform
 			const int rank = r0 + (int)seg;
@@ -1143,23 +1165,26 @@ __global__ __launch_bounds__(BLOCK, CS_WIN0_WAVES) void bwd_win0_kernel(const Sp
 			const int src = job ? (int)rank2lane[wv][rank] : (int)lane;
 			const uint32_t r = __shfl(bt.r, src), mk = __shfl((uint32_t)bt.mi_kind, src);
 			const int x = __shfl((int)bt.x, src), ret = __shfl((int)bt.ret, src);
-			const uint32_t kind = mk >> 14;
-			const uint64_t rb = job ? A.off[r] : 0;
-			PackedReader rd;
-			if (job) rd.start(A.seqp, rb, r, x);
+			const uint64_t c0w = __shfl(cw0, src), cb = __shfl(cbad, src); const uint32_t c1w = __shfl(cw1, src);
+			const int te = x + 1 + (int)gl;
+			bool pass = job && (int)gl < k - 1 && te <= ret && te - k >= 0;
 			uint32_t code = 0;
-			const bool pass = job && win_lane_filter(A, rd, gl, x, ret, code, W);
+			if (pass) {
+				const uint32_t g2 = gl << 1;
+				const uint64_t w = gl ? c0w >> g2 | (uint64_t)c1w << (64u - g2) : c0w; // the k-mer [te - k, te)
+				pass = ((uint32_t)(cb >> gl) & ((1u << k) - 1u)) == 0;              // no ambiguous base in it
+				if (pass && A.bloom) { wc_add(W, EV_BLOOM); pass = kmer_filter_has(A.bloom, A.bloom_bits, w & ((1ull << (2 * k)) - 1ull)); }
+				code = __brev((uint32_t)(w >> (2 * (k - jk))));
+				code = (((code & 0xAAAAAAAAu) >> 1) | ((code & 0x55555555u) << 1)) >> (32 - 2 * jk);
+			}
 			const uint64_t am = __ballot(pass);
 			if (npark + __popcll(am) > PARK) flush();
 			if (npark == 0) park_seq0 = bseq;
 			if (pass) {
-				WinPark p; p.r = r; p.code = code; p.te = x + 1 + (int)gl; p.mk = (uint16_t)mk; p.key = (uint16_t)((bseq & 0x3ffu) << 6 | (uint32_t)src);
+				WinPark p; p.r = r; p.code = code; p.te = te; p.mk = (uint16_t)mk; p.key = (uint16_t)((bseq & 0x3ffu) << 6 | (uint32_t)src);
 				park[wv][npark + __popcll(am & ((1ull << lane) - 1ull))] = p;
 			}
 			npark += __popcll(am);
-			uint64_t push1 = FTASK_NONE;
-			if (job && gl == 0 && kind == TK_ROUND1) push1 = chain_round1(rd, r, (int)(A.off[r + 1] - rb), ret, x);
-			wave_push<64>(O, push1 != FTASK_NONE, push1, A);
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
@@ -1192,8 +1217,11 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win_kernel(const SplitArgs A, co
 }
 
 // the calls with more than 64 LEPs, one wave each; rare, so it runs beside bwd_all_kernel on its own stream
+#ifndef CS_WIDE_BLOCKS
+#define CS_WIDE_BLOCKS 4
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void bwd_wide_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr)
+__global__ __launch_bounds__(256, CS_WIDE_BLOCKS) void bwd_wide_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr)
 {
 	if (*A.n_btasks == 0) return;
 	WaveOut O = {0, 0};
