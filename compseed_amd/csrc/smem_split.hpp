@@ -1293,18 +1293,48 @@ __device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, 
 	out.x0 = lo; out.x1 = lo2; out.x2 = hi - lo + 1;
 	return true;
 }
-__device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint64_t x0, int beg, int end, int pivot, LaneCtr &C)
+// What most calls come to: in sequence that is not repeated, rep[] stays below min_seed_len around the pivot.  If it does at
+// all the min_seed_len offsets up to the pivot (and is never 0), the sweep below ends within them (o + rep[o] <= pivot at the
+// latest at o = pivot - min_seed_len + 1), touches neither end of the SMEM and reports nothing: the call is answered by three
+// or four words of rep[].  0: answered; 1: needs the sweep; 2: the text cannot tell.  P: text position of the SMEM's first base.
+__device__ __forceinline__ int r2_quick(const SplitArgs &A, uint64_t x0, int beg, int end, int pivot, uint64_t &P, LaneCtr &C)
 {
 	const DevIndex &ix = A.ix;
 	const int len = end - beg, po = pivot - beg, k = A.min_seed_len;
-	if (k < 2 || po > 4096) return false;
+	if (k < 2 || po > 4096) return 2;
+	P = sa_direct(ix, x0);
+	++C.sa;
+	if (P >= ix.seq_len || P + (uint64_t)len > ix.seq_len) return 2; // (an SMEM lies inside the text)
+	if (po < k || po + k > len || k > 32) return 1;
+	const uint64_t lo = P + (uint64_t)(po - k + 1), hi = P + (uint64_t)po;   // the bytes rep[lo .. hi]
+	const uint64_t *wp = reinterpret_cast<const uint64_t *>(ix.rep) + (lo >> 3);
+	const uint32_t nw = (uint32_t)((hi >> 3) - (lo >> 3)) + 1u;                // 3..5 aligned words for k <= 32
+	uint64_t wd[5];
+#pragma unroll
+	for (int q = 0; q < 5; ++q) wd[q] = (uint32_t)q < nw ? wp[q] : 0x0101010101010101ull;
+	C.rep += nw;
+	const uint64_t ones = 0x0101010101010101ull, top = 0x8080808080808080ull;
+	const uint64_t fl = ((lo & 7) ? ~0ull << ((lo & 7) << 3) : ~0ull), fh = ~0ull >> ((7 - (hi & 7)) << 3); // bytes of the first / last word that count
+	uint64_t bad = 0;
+#pragma unroll
+	for (int q = 0; q < 5; ++q) {
+		const uint64_t w = wd[q];
+		uint64_t f = ((((w & ~top) + (uint64_t)(0x80 - k) * ones) | w) & top)    // a byte >= k
+		           | ((w - ones) & ~w & top);                                    // a byte == 0
+		if (q == 0) f &= fl;
+		if ((uint32_t)q + 1u == nw) f &= fh;
+		if ((uint32_t)q < nw) bad |= f;
+	}
+	return bad ? 1 : 0;
+}
+__device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint64_t P, int beg, int end, int pivot, LaneCtr &C)
+{
+	const DevIndex &ix = A.ix;
+	const int len = end - beg, po = pivot - beg, k = A.min_seed_len;
 	// Where the SMEM touches an end of the READ the sweep cannot run past it either (bwt.c:303 stops the forward pass at
 	// the last base, bwt.c:326 the backward sweep in front of the first), so there the text still tells everything: ends
 	// are clipped to the read end, and a match that is still alive at the first base is reported there.
 	const bool at_start = beg == 0, at_end = (uint64_t)end == A.off[r + 1] - A.off[r];
-	const uint64_t P = sa_direct(ix, x0); // text position of read base `beg`
-	++C.sa;
-	if (P >= ix.seq_len || P + (uint64_t)len > ix.seq_len) return false; // (an SMEM lies inside the text)
 	// rep[] of the SMEM's bases, eight per aligned load; the window covers the offsets [wo, wo + 8) of the SMEM (32-bit arithmetic:
 	// the walk is this kernel's inner loop, and a wave runs as long as its longest walk)
 	const uint8_t *rp = ix.rep + P;
@@ -1352,23 +1382,50 @@ __global__ __launch_bounds__(256, CS_R2_WAVES) void r2text_kernel(const SplitArg
 	const uint32_t lane = threadIdx.x & 63u;
 	unsigned long long done = 0, left = 0;
 	LaneCtr C = {0, 0, 0, 0, 0};
-	// a wave takes 256 consecutive slots at a time (one atomic on the output counter per 256 slots)
+	// a wave takes 256 consecutive slots at a time (one atomic on the output counter per 256 slots).  The quick test settles
+	// most candidates; the others are gathered (LDS) and swept together on full waves afterwards -- the sweep is a loop of up
+	// to a few dozen steps, and a wave runs as long as its longest.
+	__shared__ uint64_t slow_P[256 / 64][256];
+	__shared__ uint8_t slow_src[256 / 64][256], slow_ok[256 / 64][256];
+	const uint32_t wv = threadIdx.x >> 6;
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
 	for (uint64_t t0 = wave * 256; t0 < n; t0 += n_waves * 256) { // wave-uniform
-		uint64_t task[4]; uint64_t km[4]; uint32_t total = 0;
+		uint64_t task[4]; uint64_t km[4]; uint32_t total = 0, nslow = 0, slowm = 0;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const uint64_t t = t0 + (uint64_t)(64 * j) + lane;
 			task[j] = t < n ? fq[t] : FTASK_NONE;
+			bool slow = false; uint64_t P = 0;
 			if ((uint32_t)(task[j] >> 62) == TK_ROUND2 && ((task[j] >> 48) & 0x3fffu) == 2u) {
-				uint64_t a = aux[t];
-				uint32_t r = (uint32_t)task[j]; int pivot = (int)((task[j] >> 32) & 0xffffu);
-				int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
-				if (r2_by_text(A, r, a & ((1ull << 37) - 1ull), beg, end, pivot, C)) { task[j] = FTASK_NONE; ++done; } else ++left;
+				const uint64_t a = aux[t];
+				const int pivot = (int)((task[j] >> 32) & 0xffffu);
+				const int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
+				const int q = r2_quick(A, a & ((1ull << 37) - 1ull), beg, end, pivot, P, C);
+				if (q == 0) { task[j] = FTASK_NONE; ++done; } else if (q == 1) slow = true; else ++left;
 			}
+			const uint64_t sm = __ballot(slow);
+			if (slow) { const uint32_t i = nslow + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull)); slow_P[wv][i] = P; slow_src[wv][i] = (uint8_t)(64 * j + (int)lane); slowm |= 1u << j; }
+			nslow += (uint32_t)__popcll(sm);
+		}
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t c = 0; c < nslow; c += 64) { // wave-uniform
+			const uint32_t i = c + lane;
+			if (i < nslow) {
+				const uint32_t src = slow_src[wv][i];
+				const uint64_t t = t0 + src, tk = fq[t], a = aux[t];
+				const int pivot = (int)((tk >> 32) & 0xffffu);
+				const int beg = (int)((a >> 37) & 0xffffu), end = 2 * pivot + (int)((a >> 53) & 1u) - beg;
+				slow_ok[wv][src] = r2_by_text(A, (uint32_t)tk, slow_P[wv][i], beg, end, pivot, C) ? 1 : 0;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (slowm & (1u << j)) { if (slow_ok[wv][64 * j + (int)lane]) { task[j] = FTASK_NONE; ++done; } else ++left; }
 			km[j] = __ballot(task[j] != FTASK_NONE);
 			total += (uint32_t)__popcll(km[j]);
 		}
+		__builtin_amdgcn_wave_barrier();
 		if (total) {
 			unsigned long long base = 0;
 			if (lane == 0) base = atomicAdd(n_out, (unsigned long long)total);
