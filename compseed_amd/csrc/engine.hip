@@ -874,19 +874,33 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	uint32_t max_len = (uint32_t)e->h_ctr.p[3];
 	if (e->h_ctr.p[3] >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
 
-	// ASCII -> nt4 into a private padded buffer (the caller's reads stay untouched)
-	CS_TRY(e->d_seq.reserve((size_t)n_bases + 64));
-	if (n_bases) {
-		unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256, (uint64_t)e->n_cu * 16);
-		hipLaunchKernelGGL(nt4_kernel, dim3(g), dim3(256), 0, s, d_bases, e->d_seq.p, n_bases);
-	}
-	HIP_TRY(hipMemsetAsync(e->d_seq.p + n_bases, 4, 64, s));
-	if (e->smem_mode == 1) { // the split kernels read the packed copy (32 bases per 16-byte record)
-		CS_TRY(e->d_seqp.reserve((size_t)(n_bases >> 5) + (size_t)n_reads + 4));
-		hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads * 8, 256), (int64_t)e->n_cu * 16)), dim3(256), 0, s, e->d_seq.p, d_off, n_reads, e->d_seqp.p);
+	// The split kernels read the reads as 16-byte records of 32 bases (pack_reads_kernel), made straight from the caller's bytes
+	// (which stay untouched).  The byte-per-base nt4 copy is what the fused kernel reads: made only when that one runs.
+	const bool raw_ok = e->smem_mode == 1 && ((uintptr_t)d_bases & 7u) == 0;
+	bool have_nt4 = false;
+	auto make_nt4 = [&]() -> int {
+		if (have_nt4) return CS_OK;
+		CS_TRY(e->d_seq.reserve((size_t)n_bases + 64));
+		if (n_bases) {
+			unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256, (uint64_t)e->n_cu * 16);
+			hipLaunchKernelGGL(nt4_kernel, dim3(g), dim3(256), 0, s, d_bases, e->d_seq.p, n_bases);
+		}
+		HIP_TRY(hipMemsetAsync(e->d_seq.p + n_bases, 4, 64, s));
+		have_nt4 = true;
+		return CS_OK;
+	};
+	if (!raw_ok) CS_TRY(make_nt4());
+	const uint64_t n_rec = (n_bases >> 5) + (uint64_t)n_reads;
+	if (e->smem_mode == 1) {
+		CS_TRY(e->d_seqp.reserve((size_t)n_rec + 4));
+		const dim3 gp((unsigned)std::min<int64_t>(grid_for(n_reads * 8, 256), (int64_t)e->n_cu * 16));
+		if (raw_ok) hipLaunchKernelGGL(pack_reads_kernel<true>, gp, dim3(256), 0, s, d_bases, d_off, n_reads, n_bases, e->d_seqp.p);
+		else hipLaunchKernelGGL(pack_reads_kernel<false>, gp, dim3(256), 0, s, (const uint8_t *)e->d_seq.p, d_off, n_reads, n_bases, e->d_seqp.p);
 		e->off_base = d_off;
-		e->stream_bytes += n_bases + 16 * ((n_bases >> 5) + (uint64_t)n_reads);
 	}
+	// byte model, stream part: the bases are read once (twice and written once where the nt4 copy is made), the records written, and
+	// read by the forward, backward and round-3 kernels
+	e->stream_bytes += n_bases * (raw_ok ? 1 : 3) + (e->smem_mode == 1 ? 16 * n_rec * 4 : n_bases * 3);
 
 	const uint32_t cap = e->cap;
 	int64_t per_launch = (int64_t)std::max<size_t>(1024, e->max_raw_bytes / ((size_t)cap * sizeof(OutMem)));
@@ -931,6 +945,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 			}
 			// rc == 1: a task queue overflowed -- redo this sub-batch with the fused kernel
 		}
+		CS_TRY(make_nt4()); // (the fused kernel reads a byte per base)
 		HIP_TRY(hipMemsetAsync(e->d_cnt.p + nb, 0, sizeof(uint32_t), s));
 		CS_TRY(launch_smem(e, par, d_off + b0, nullptr, nb, e->d_out.p, e->d_cnt.p, cap, max_len));
 		HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, sizeof(unsigned long long), s));
@@ -1004,9 +1019,13 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		HIP_TRY(hipStreamSynchronize(s));
 		uint64_t total_seeds = e->h_ctr.p[0];
 		CS_TRY(e->d_seeds.reserve((size_t)total_seeds + 16));
-		if (total_mems)
-			hipLaunchKernelGGL(sal_expand_kernel, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->d_mems.p, total_mems,
-			                   (uint32_t)par->max_occ, som.p, e->d_seeds.p);
+		const bool fused_gather = !e->opt.count_sal_merged && (e->ix.fsa32 || e->ix.fsa64); // (the merged-call statistic needs the slots)
+		if (total_mems) {
+			if (fused_gather) hipLaunchKernelGGL(sal_expand_kernel<true>, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->ix, e->d_mems.p, total_mems,
+			                                     (uint32_t)par->max_occ, som.p, e->d_seeds.p);
+			else hipLaunchKernelGGL(sal_expand_kernel<false>, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->ix, e->d_mems.p, total_mems,
+			                        (uint32_t)par->max_occ, som.p, e->d_seeds.p);
+		}
 		hipLaunchKernelGGL(seed_off_kernel, dim3(grid_for(n_reads + 1, 256)), dim3(256), 0, s, e->d_mem_off.p, som.p, n_reads, e->d_seed_off.p);
 		uint64_t sal_calls = total_seeds;
 		if (e->opt.count_sal_merged && total_seeds) { // statistics option; the slots are still in rbeg here (the gather below overwrites them)
@@ -1026,7 +1045,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 			HIP_TRY(hipStreamSynchronize(s));
 			sal_calls = e->h_ctr.p[5];
 		}
-		if (total_seeds) {
+		if (total_seeds && !fused_gather) {
 			if (e->ix.fsa32 || e->ix.fsa64)
 				hipLaunchKernelGGL(sal_gather_kernel, dim3(grid_for((int64_t)total_seeds, 256)), dim3(256), 0, s, e->ix, e->d_seeds.p, total_seeds);
 			else
@@ -1043,9 +1062,8 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	HIP_TRY(hipStreamSynchronize(s));
 	CS_TRY(add_event_ms(e, e->ev[2], e->ev[3], &e->st.total_ms));
 	e->st.reads += (uint64_t)n_reads; e->st.bases += n_bases; e->st.mems += total_mems; e->st.seeds += *n_seeds_out;
-	// byte model, stream part: nt4 conversion reads and writes every base, the forward, backward and round-3 kernels each read
-	// it once more; a mem is written raw, read by the sort and written again (32 B each)
-	e->stream_bytes += n_bases * 5 + total_mems * 96;
+	// byte model, stream part: a mem is written raw, read by the sort and written again (32 B each)
+	e->stream_bytes += total_mems * 96;
 	return CS_OK;
 }
 

@@ -277,7 +277,9 @@ __global__ void sal_count_kernel(const OutMem *mems, uint64_t n_mems, uint32_t m
 
 struct OutSeed { int64_t rbeg; int32_t qbeg, len; }; // == cs_seed_t
 
-__global__ void sal_expand_kernel(const OutMem *mems, uint64_t n_mems, uint32_t max_occ, const uint64_t *seed_of_mem, OutSeed *seeds)
+// GATHER: the slot is looked up in the HBM-resident full suffix array right here (one pass over the seeds instead of two)
+template <bool GATHER>
+__global__ void sal_expand_kernel(const DevIndex ix, const OutMem *mems, uint64_t n_mems, uint32_t max_occ, const uint64_t *seed_of_mem, OutSeed *seeds)
 {
 	uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= n_mems) return;
@@ -287,7 +289,7 @@ __global__ void sal_expand_kernel(const OutMem *mems, uint64_t n_mems, uint32_t 
 	int32_t qb = (int32_t)(v.info >> 32), ln = (int32_t)(uint32_t)v.info - qb;
 	uint64_t cntr = 0;
 	for (uint64_t k = 0; k < v.x2 && cntr < max_occ; k += step, ++cntr) {
-		OutSeed s = {(int64_t)(v.x0 + k), qb, ln};
+		OutSeed s = {GATHER ? (int64_t)sa_direct(ix, v.x0 + k) : (int64_t)(v.x0 + k), qb, ln};
 		dst[cntr] = s;
 	}
 }

@@ -180,7 +180,10 @@ __global__ void jump_fill_kernel(const DevIndex ix, int k, uint4 *table)
 // len exists and says "end" there.  Why: at 6-8 waves per SIMD the lanes in flight touch more lines than the L2 holds, so every
 // 8-byte window of a byte-per-base read and every 4-byte word of the text came from HBM again (fwd0_kernel fetched 30 lines per
 // read for 12 lines' worth of data); with 32 bases per load there is one fetch per record.
-__global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64_t n_reads, uint4 *rec)
+// RAW: straight from the caller's bytes (ASCII or nt4 codes; nst_nt4_table, FM_index/bntseq.c:46-63, codes 0..4 pass through as in
+// comp_seed.cpp:2259) -- the byte-per-base nt4 copy is then only made when the fused kernel has to step in.  n_bases bounds the loads.
+template <bool RAW>
+__global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64_t n_reads, uint64_t n_bases, uint4 *rec)
 {
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = ((uint64_t)gridDim.x * blockDim.x) >> 3;
 	for (uint64_t r = gid >> 3; r < (uint64_t)n_reads; r += gstride) { // eight lanes per read, a record each
@@ -189,16 +192,27 @@ __global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64
 		for (uint64_t k = gid & 7; k < nrec; k += 8) {
 			uint4 o = {0u, 0u, ~0u, 0u};
 			if (k * 32 < len) {
-				const uint64_t a = rb + k * 32, a0 = a & ~7ull;                // (the nt4 copy is padded by 64 bytes)
+				const uint64_t a = rb + k * 32, a0 = a & ~7ull;                // (the nt4 copy is padded by 64 bytes; the caller's buffer is not)
 				const uint64_t *w = reinterpret_cast<const uint64_t *>(seq + a0);
 				const uint32_t sh = (uint32_t)(a - a0) << 3;
 				uint64_t v[5];
 #pragma unroll
-				for (int q = 0; q < 5; ++q) v[q] = w[q];
+				for (int q = 0; q < 5; ++q) v[q] = (!RAW || a0 + 8u * (uint32_t)q < n_bases) ? w[q] : 0x0404040404040404ull;
 				uint64_t bases = 0; uint32_t bad = 0;
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
 					uint64_t b8 = sh ? (v[q] >> sh) | (v[q + 1] << (64u - sh)) : v[q]; // bases 8q .. 8q+7, a byte each
+					if (RAW) { // letters -> codes: ((c >> 1) ^ (c >> 2)) & 3 for A C G T in either case, 4 for everything else but the codes 0..3
+						uint64_t c8 = 0;
+#pragma unroll
+						for (int z = 0; z < 8; ++z) {
+							const uint32_t c = (uint32_t)(b8 >> (8 * z)) & 0xffu, t = (c & 0xdfu) - 0x41u;
+							const bool letter = t < 20u && ((0x80045u >> t) & 1u);
+							const uint32_t code = c < 4u ? c : letter ? ((c >> 1) ^ (c >> 2)) & 3u : 4u;
+							c8 |= (uint64_t)code << (8 * z);
+						}
+						b8 = c8;
+					}
 					bad |= (uint32_t)((((b8 >> 2) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * q);
 					b8 &= 0x0303030303030303ull;
 					b8 = (b8 | (b8 >> 6)) & 0x000F000F000F000Full;
