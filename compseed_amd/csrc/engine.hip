@@ -125,6 +125,7 @@ struct cs_engine {
 	DevBuf<uint32_t> d_fsa32; DevBuf<uint64_t> d_fsa64; // full suffix array (one of the two)
 	DevBuf<uint32_t> d_text2, d_isa32; DevBuf<uint64_t> d_isa64; // text mode: 2-bit text + inverse suffix array
 	DevBuf<uint64_t> d_bloom; int bloom_k = 0; uint32_t bloom_bits = 0; // k-mer filter of the text for the min_seed_len in use (built on first use)
+	DevBuf<uint8_t> d_pending; // r3text_kernel: reads with calls of rounds 1/2 still queued when it starts
 	DevBuf<uint32_t> d_cnt_snap; DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
 	// inputs
 	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off; DevBuf<uint4> d_seqp; const uint64_t *off_base = nullptr; // d_seqp: pack_reads_kernel's records for the batch whose offsets start at off_base
@@ -441,7 +442,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	(void)hipSetDevice(e->device);
 	pipe_stop(e);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_seqp.release(); e->d_off.release();
+	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_pending.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_seqp.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
 	e->d_mems.release(); e->d_seeds.release();
@@ -757,13 +758,16 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 	// still cost a launch chain and a host round trip each); it works from a snapshot of the mem counts
 	const int r3t_iter = e->opt.r3_text_iter; // measured: 2: 67.8, 3: 66.9, 4: 66.0, 5: 66.8, 6: 68.0 ms
 	bool r3t_launched = false;
-	if (r3_text) CS_TRY(e->d_cnt_snap.reserve((size_t)nb + 1));
-	auto launch_r3text = [&]() -> int {
+	if (r3_text) { CS_TRY(e->d_cnt_snap.reserve((size_t)nb + 1)); CS_TRY(e->d_pending.reserve((size_t)nb + 1)); }
+	auto launch_r3text = [&](const uint64_t *queue, const unsigned long long *queue_n) -> int {
+		// which reads still have calls in the queue (their mem lists are not final; for all others the text answers everything)
+		HIP_TRY(hipMemsetAsync(e->d_pending.p, 0, (size_t)nb, s));
+		if (queue) hipLaunchKernelGGL(mark_pending_kernel, dim3((unsigned)e->n_cu * 4), dim3(256), 0, s, queue, queue_n, fq_cap, nb, e->d_pending.p);
 		HIP_TRY(hipEventRecord(e->ev_r3a, s));
 		HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_r3a, 0));
 		HIP_TRY(hipMemcpyAsync(e->d_cnt_snap.p, e->d_cnt.p, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream2));
 		hipLaunchKernelGGL(r3text_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 16, ((uint64_t)nb + 255) / 256)), dim3(256), 0, e->stream2, A,
-		                   (const uint32_t *)e->d_cnt_snap.p, C + 15);
+		                   (const uint32_t *)e->d_cnt_snap.p, C + 15, (const uint8_t *)e->d_pending.p);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(e->ev_r3b, e->stream2));
 		return CS_OK;
@@ -821,7 +825,9 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 			                   (const unsigned long long *)(C + 1), C + 11, C + 12, cur, C + 16);
 			HIP_TRY(hipGetLastError());
 		}
-		if (r3_text && !r3t_launched && iter + 1 >= r3t_iter) { CS_TRY(launch_r3text()); r3t_launched = true; }
+		if (r3_text && !r3t_launched && iter + 1 >= r3t_iter) { // (the queue of the next iteration: what r2text_kernel has left, or what was pushed)
+			CS_TRY(launch_r3text(r2text ? cur : nxt, r2text ? C + 16 : C + 1)); r3t_launched = true;
+		}
 		CS_TRY(fetch_words(e->h_sctr, 0, C, 32, s));
 		HIP_TRY(hipStreamSynchronize(s));
 		if (H[7]) return 1; // a queue or the overflow records ran full: the caller redoes the sub-batch with the fused kernel
@@ -834,7 +840,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 		if (!r2text) { std::swap(cur, nxt); std::swap(aux_cur, aux_nxt); } // (r2text_kernel has compacted the next queue into `cur`)
 		if (iter > (int)max_len + 8) return fail(CS_EDEVICE, "SMEM task chain did not terminate"); // a read has at most len pivots
 	}
-	if (r3_text && !r3t_launched) { CS_TRY(launch_r3text()); r3t_launched = true; }
+	if (r3_text && !r3t_launched) { CS_TRY(launch_r3text(nullptr, nullptr)); r3t_launched = true; }
 	if (r3_async && !r3_launched) { CS_TRY(launch_r3()); r3_launched = true; }
 	if (r3_async || r3_text) HIP_TRY(hipStreamWaitEvent(s, e->ev_r3b, 0)); // join the round-3 stream
 	HIP_TRY(hipEventRecord(e->ev[1], s));

@@ -1474,11 +1474,12 @@ __global__ __launch_bounds__(256, CS_R2_WAVES) void r2text_kernel(const SplitArg
 // 1 + #{neighbours sharing >= L} occurrences, so L = 1 + the (max_intv - 1)-th largest shared length (or k1 if fewer than
 // that many neighbours share k1 bases).  At most max_intv - 1 bytes of lcp[] on either side: two cache lines instead of the
 // dozens of bwt_extend calls such a seed costs in a repeat.  False when a capped value (255) would decide.
-__device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int k1, uint32_t max_intv, int &L, LaneCtr &C)
+// 0: the arrays cannot tell; 1: L; 2: max_intv - 1 neighbours share 255 bases or more (every prefix of up to 254 bases has max_intv occurrences)
+__device__ __forceinline__ int r3_text_len(const DevIndex &ix, uint64_t p, int k1, uint32_t max_intv, int &L, LaneCtr &C)
 {
-	if (max_intv < 2 || max_intv > 41) return false;
+	if (max_intv < 2 || max_intv > 41) return 0;
 	const uint32_t m = max_intv - 1;
-	if (p >= ix.seq_len) return false;
+	if (p >= ix.seq_len) return 0;
 	uint64_t up = isa_direct(ix, p), dn = up + 1;
 	LcpReader Lu = {ix.lcp, ~0ull, 0, 0}, Ld = {ix.lcp, ~0ull, 0, 0}; // one window per side: ~3 dependent loads instead of up to 19
 	struct Tally { LcpReader &A, &B; LaneCtr &C; __device__ ~Tally() { C.lcp += LcpReader::BYTES * (A.loads + B.loads); } } tally = {Lu, Ld, C};
@@ -1486,13 +1487,13 @@ __device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int 
 	++C.isa;
 	for (uint32_t t = 0; t < m; ++t) {
 		val = mu > md ? mu : md;
-		if (val < (uint32_t)k1) { L = k1; return true; }   // fewer than max_intv occurrences already at k1 bases
-		if (mu >= md) { if (up == 0) return false; --up; const uint32_t c = Lu.at(up); mu = c < mu ? c : mu; }
-		else { if (dn > ix.seq_len) return false; ++dn; const uint32_t c = Ld.at(dn); md = c < md ? c : md; }
+		if (val < (uint32_t)k1) { L = k1; return 1; }      // fewer than max_intv occurrences already at k1 bases
+		if (mu >= md) { if (up == 0) return 0; --up; const uint32_t c = Lu.at(up); mu = c < mu ? c : mu; }
+		else { if (dn > ix.seq_len) return 0; ++dn; const uint32_t c = Ld.at(dn); md = c < md ? c : md; }
 	}
-	if (val >= 255u) return false;                          // the true shared length is not known
+	if (val >= 255u) return 2;                              // the true shared length is not known
 	L = (int)val + 1;
-	return true;
+	return 1;
 }
 
 // cnt_snap: the per-read mem counts at a moment when every entry below them was complete (a copy taken between launches):
@@ -1501,7 +1502,19 @@ __device__ __forceinline__ bool r3_text_len(const DevIndex &ix, uint64_t p, int 
 #ifndef CS_R3_WAVES
 #define CS_R3_WAVES 5
 #endif
-__global__ __launch_bounds__(256, CS_R3_WAVES) void r3text_kernel(const SplitArgs A, const uint32_t *cnt_snap, unsigned long long *n_text_seeds)
+// reads that still have calls of rounds 1/2 in the queue when r3text_kernel starts: their mem lists are not final
+__global__ void mark_pending_kernel(const uint64_t *fq, const unsigned long long *n_ptr, uint64_t cap, int64_t n_reads, uint8_t *pending)
+{
+	uint64_t n = *n_ptr; if (n > cap) n = cap;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t task = fq[t];
+		if ((uint32_t)(task >> 62) != TK_NOP && (int64_t)(uint32_t)task < n_reads) pending[(uint32_t)task] = 1;
+	}
+}
+// `pending[r] == 0` and no more than `cap` mems: every SMEM of the read is in its list.  Then the text answers everything: the mem that
+// covers [x, x + k1) and reaches furthest to the right ends where the longest match from x ends (a longer one would sit in an SMEM of
+// its own, which would be in the list), and if no mem covers it the k1-mer does not occur at all.
+__global__ __launch_bounds__(256, CS_R3_WAVES) void r3text_kernel(const SplitArgs A, const uint32_t *cnt_snap, unsigned long long *n_text_seeds, const uint8_t *pending)
 {
 	const DevIndex &ix = A.ix;
 	const int k1 = A.min_seed_len + 1;
@@ -1511,24 +1524,38 @@ __global__ __launch_bounds__(256, CS_R3_WAVES) void r3text_kernel(const SplitArg
 	WaveCtr W;
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
 		const uint64_t rb = A.off[r]; const int len = (int)(A.off[r + 1] - rb);
-		const uint32_t nm0 = cnt_snap[r] < A.cap ? cnt_snap[r] : A.cap; // the mems of rounds 1 and 2 known to be complete
+		const uint32_t cs = cnt_snap[r], nm0 = cs < A.cap ? cs : A.cap; // the mems of rounds 1 and 2 known to be complete
+		const bool complete = pending[r] == 0 && cs <= A.cap;
 		const OutMem *mine = A.out + (size_t)r * A.cap;
 		int cb = 0, ce = 0; uint64_t cp = 0; // the mem the cursor is in: [cb, ce) at text position cp
+		bool covered = false;
 		int x = 0;
 		PackedReader rd; rd.start(A.seqp, rb, (uint32_t)r, 0);
 		while (x < len) {
 			if (rd.at(x) > 3) { ++x; continue; }
 			if (!(x >= cb && x + k1 <= ce)) { // look for a mem that covers [x, x + k1)
 				cb = ce = 0;
-				for (uint32_t a = 0; a < nm0; ++a) {
+				int best = -1;
+				for (uint32_t a = 0; a < nm0; ++a) { // the one that reaches furthest (any occurrence of it will do)
 					const uint64_t info = mine[a].info; const int mb = (int)(info >> 32), me = (int)(uint32_t)info;
 					++C.mem;
-					if (x >= mb && x + k1 <= me) { // any occurrence will do
-						cb = mb; ce = me; cp = sa_direct(ix, mine[a].x0); ++C.sa;
-						if (cp >= ix.seq_len || cp + (uint64_t)(me - mb) > ix.seq_len) cb = ce = 0; // (a mem lies inside the text)
-						break;
-					}
+					if (x >= mb && x + k1 <= me && me > ce) { best = (int)a; cb = mb; ce = me; }
 				}
+				covered = best >= 0;
+				if (covered) {
+					cp = sa_direct(ix, mine[best].x0); ++C.sa;
+					if (cp >= ix.seq_len || cp + (uint64_t)(ce - cb) > ix.seq_len) cb = ce = 0; // (a mem lies inside the text)
+				}
+			}
+			if (complete && !covered) { // [x, x + k1) does not occur (or is cut short by an ambiguous base or the read's end): bwt.c:366-377
+				uint32_t badw; const int nb = len - x < k1 ? len - x : k1;   // walks on to x + k1, the ambiguous base or the end, reports nothing
+				(void)rd.window(x, nb, badw);
+				const int fb = badw ? __ffs((int)badw) - 1 : 32;
+				int nx = fb < k1 ? x + fb + 1 : x + k1;
+				if (nx > len) nx = len;
+				my_q += (unsigned)(nx - x - 1); my_hits += (unsigned)(nx - x - 1);
+				x = nx;
+				continue;
 			}
 			if (x >= cb && x + k1 <= ce && ix.rep) {
 				const uint64_t p = cp + (uint64_t)(x - cb);
@@ -1575,8 +1602,36 @@ __global__ __launch_bounds__(256, CS_R3_WAVES) void r3text_kernel(const SplitArg
 				++C.rep;
 				if (v < (uint32_t)k1) { iv.x0 = isa_direct(ix, p); iv.x1 = isa_direct(ix, ix.seq_len - (p + (uint64_t)k1)); iv.x2 = 1; ok = true; C.isa += 2; }
 				int L = k1;
-				if (!ok && k1 < 255 && r3_text_len(ix, p, k1, (uint32_t)(A.max_mem_intv > 0xffffffffull ? 0xffffffffull : A.max_mem_intv), L, C) && x + L <= ce)
-					ok = text_interval(ix, p, (uint32_t)L, iv, C) && iv.x2 < A.max_mem_intv;
+				if (!ok && k1 < 255) {
+					const int st = r3_text_len(ix, p, k1, (uint32_t)(A.max_mem_intv > 0xffffffffull ? 0xffffffffull : A.max_mem_intv), L, C);
+					if (st == 1 && x + L <= ce) ok = text_interval(ix, p, (uint32_t)L, iv, C) && iv.x2 < A.max_mem_intv;
+					else if (ce == len && ((st == 1 && x + L > ce) || (st == 2 && ce - x <= 254))) {
+						// Every prefix of [x, len) has max_mem_intv occurrences or more (the mem reaches the read's end, so the read is the
+						// text all the way): bwt.c:366-377 walks to the end without reporting -- reads from tandem arrays and young
+						// duplications, each such walk a chain of a hundred extensions.  Round 3 is over for this read.
+						my_q += (unsigned)(len - x - 1); my_hits += (unsigned)(len - x - 1);
+						x = len;
+						continue;
+					} else if (complete && ((st == 1 && x + L > ce) || (st == 2 && ce - x <= 254))) {
+						// ... and where the mem ends inside the read, the longest match from x ends with it -- if no other mem covers x
+						// and reaches further (this one was picked for an earlier x): one base more and nothing is left, which is below
+						// max_mem_intv but reports nothing either (bwt.c:370-371)
+						int best = -1, bmb = cb, bme = ce;
+						for (uint32_t a = 0; a < nm0; ++a) {
+							const uint64_t info = mine[a].info; const int mb = (int)(info >> 32), me = (int)(uint32_t)info;
+							++C.mem;
+							if (x >= mb && x + k1 <= me && me > bme) { best = (int)a; bmb = mb; bme = me; }
+						}
+						if (best < 0) {
+							my_q += (unsigned)(ce - x); my_hits += (unsigned)(ce - x);
+							x = ce + 1;
+							continue;
+						}
+						cb = bmb; ce = bme; cp = sa_direct(ix, mine[best].x0); ++C.sa;
+						if (!(cp >= ix.seq_len || cp + (uint64_t)(ce - cb) > ix.seq_len)) continue; // the same question again, inside that mem
+						cb = ce = 0;                                                                // (cannot happen; then the index answers)
+					}
+				}
 				if (ok) {
 					emit_mem(A, (uint32_t)r, iv, (uint32_t)x, (uint32_t)(x + L));
 					my_q += (unsigned)(L - 1); my_hits += (unsigned)(L - 1); ++my_text;
