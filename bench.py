@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (cs_engine_seed_batch)")
     ap.add_argument("--sst", type=int, default=1, help="on-device SST memo and every shortcut (1 = on, 0 = the literal algorithm)")
     ap.add_argument("--disable", default="", help="comma-separated shortcuts to switch off (cs_params_t.disable): " +
-                    "text_mode,r2_text,text_sweep,window,r3_text,kmer_filter,fwd0,persist")
+                    "text_mode,r2_text,text_sweep,window,r3_text,kmer_filter,fwd0")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (cs_engine_options_t), repeatable")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--check-reads", type=int, default=20000, help="reads per rank compared bit-for-bit against the oracle (strided sample)")

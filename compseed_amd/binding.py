@@ -42,7 +42,7 @@ class Params(C.Structure):
 
 
 # cs_params_t.disable bits (include/compseed_amd.h CS_DISABLE_*)
-DISABLE = dict(text_mode=0x01, r2_text=0x02, text_sweep=0x04, window=0x08, r3_text=0x10, kmer_filter=0x20, fwd0=0x40, persist=0x80)
+DISABLE = dict(text_mode=0x01, r2_text=0x02, text_sweep=0x04, window=0x08, r3_text=0x10, kmer_filter=0x20, fwd0=0x40)
 
 
 def disable_mask(*names):

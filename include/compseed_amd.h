@@ -75,7 +75,6 @@ typedef struct {
 #define CS_DISABLE_R3_TEXT      0x10u  /* round-3 seeds inside a mem taken from the text arrays                               */
 #define CS_DISABLE_KMER_FILTER  0x20u  /* k-mer filter in front of the window lanes                                           */
 #define CS_DISABLE_FWD0         0x40u  /* separate lean kernel for the calls at the first base of each read                   */
-#define CS_DISABLE_PERSIST      0x80u  /* device-driven late iterations (one launch for the thin tail of the task chain)      */
 
 /* engine construction options: which derived arrays are materialised in HBM and how the working buffers are sized.
  * cs_engine_options_default() fills the defaults (in brackets).  Everything optional is also skipped automatically when
