@@ -186,7 +186,9 @@ void cs_engine_destroy(cs_engine_t *e);
  *      memory.  Device variant: pointers are device memory on the engine's GPU and the result arrays are device
  *      pointers (no PCIe traffic inside the call).  The engine works on streams of its own: device inputs must be
  *      COMPLETE when the call is made (synchronise the stream that produced them first), d_offsets[0] must be 0 and
- *      d_offsets[n_reads] == n_bases (checked: CS_EINVAL); results are complete when the call returns. */
+ *      d_offsets[n_reads] == n_bases (checked: CS_EINVAL); results are complete when the call returns.  The base
+ *      buffer is read in aligned 8-byte words: it must be readable up to the next multiple of 8 behind n_bases (any
+ *      device allocation is). */
 int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                           const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
 int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
@@ -291,8 +293,9 @@ int  cs_engine_gather_reads(cs_engine_t *e, int64_t n_sel, const uint64_t *read_
 typedef struct {
 	uint64_t events[CS_N_KERNELS][CS_N_EVENTS];
 	uint64_t event_bytes[CS_N_EVENTS];
-	uint64_t stream_bytes;   /* modelled on the host per call: read bases (nt4 conversion + one pass per kernel family), task
-	                            queue words, backward task records, raw mems written, sorted and written again */
+	uint64_t stream_bytes;   /* modelled on the host per call: read bases read once, their packed records written and read by
+	                            each kernel family, task queue words, backward task records, raw mems written, sorted and
+	                            written again */
 } cs_traffic_t;
 int  cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out);
 
