@@ -82,6 +82,34 @@ def test_device_variant_equals_host_variant(eng):
     eng.free(d_b); eng.free(d_o)
 
 
+NT4_LUT = np.full(256, 4, np.uint8)   # nst_nt4_table restricted to what pack_reads_kernel distinguishes: A C G T in either case
+for _i, _ch in enumerate(b"ACGT"):
+    NT4_LUT[_ch] = _i; NT4_LUT[_ch | 0x20] = _i
+
+
+def test_unaligned_and_coded_device_inputs(eng):
+    """pack_reads_kernel reads the caller's bytes in aligned 8-byte words when the pointer allows it and goes through the nt4 copy
+    when it does not; ASCII (either case, IUPAC, '-') and 0..4 codes are the same reads (comp_seed.cpp:2258-2260)"""
+    import compseed_amd as ca
+    for name in ("ragged", "main100"):
+        bases, off = _data.load_reads(name)
+        want = eng.seed_batch(bases, off)
+        d_o = eng.alloc(off.nbytes); eng.upload(d_o, off)
+        for shift in (0, 3):
+            for coded in (False, True):
+                b = NT4_LUT[bases] if coded else bases
+                d_b = eng.alloc(b.nbytes + 80)
+                eng.upload(d_b + shift, b)
+                dev = eng.seed_batch_device(d_b + shift, d_o, off.size - 1, b.size)
+                assert dev.n_mems == want.n_mems and dev.n_seeds == want.n_seeds, (name, shift, coded)
+                assert np.array_equal(eng.download(dev.ptr["mem_off"], np.uint64, off.size), want.mem_off)
+                assert np.array_equal(eng.download(dev.ptr["mems"], ca.INTV_DT, dev.n_mems), want.mems), (name, shift, coded)
+                assert np.array_equal(eng.download(dev.ptr["seeds"], ca.SEED_DT, dev.n_seeds), want.seeds), (name, shift, coded)
+                assert np.array_equal(eng.download(d_b + shift, np.uint8, b.size), b)      # untouched
+                eng.free(d_b)
+        eng.free(d_o)
+
+
 def test_empty_and_degenerate_batches(eng):
     r = eng.seed_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     assert r.n_reads == 0 and r.n_mems == 0 and r.n_seeds == 0
