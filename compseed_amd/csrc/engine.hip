@@ -798,8 +798,9 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 				HIP_TRY(hipMemsetAsync(C + 2, 0, 4 * sizeof(unsigned long long), s));
 				HIP_TRY(hipEventRecord(e->ev_wa, s)); // forward launch done, counters zeroed
 				HIP_TRY(hipStreamWaitEvent(e->stream3, e->ev_wa, 0));
-				// side streams: the calls with more than 46 / 64 LEPs, one wave each (few on a mostly unique genome, many on a repeat-rich one:
-				// four blocks per CU so that they overlap their list reads), and the calls without stored LEPs (the bulk of the calls)
+				// side streams: the calls with more than 46 / 64 LEPs, one wave each (few on a mostly unique genome, many on a repeat-rich one;
+				// chains of dependent reads, so what counts is waves in flight: six blocks per CU, registers spilled and all, run a
+				// repeat-rich genome 6 % faster than four), and the calls without stored LEPs (the bulk of the calls)
 				HIP_TRY(hipStreamWaitEvent(e->stream4, e->ev_wa, 0));
 				if (count) hipLaunchKernelGGL(bwd_wide_kernel<true>, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * CS_WIDE_BLOCKS, (cn + 255) / 256)), dim3(256), 0, e->stream4, A,
 				                              (const BTask *)e->d_bq.p, cn, C + 5);

@@ -960,7 +960,35 @@ __device__ __forceinline__ void bwd_wide_run(const SplitArgs &A, const BTask *bq
 		uint4 *lep = A.lep + (size_t)t * A.lep_stride;
 		PackedReader rd; rd.start(A.seqp, A.off[r], r, (int)bt.x - 1);
 		int n = bt.n, lo = 0, nm = 0, last_start = 0, f_long = 0x7fffffff;
-		for (int i = (int)bt.x - 1; i >= -1; --i) {
+		if (n <= 64) { // the whole list fits the wave: lane g holds LEP n-1-g in registers, nothing is streamed (same rules; no compaction:
+			// the longest live match is the lowest live lane, the previous survivor the nearest surviving lane below)
+			bool live = (int)lane < n;
+			Intv p = {0, 0, 0}; uint32_t pend = 0;
+			if (live) { unpack_lep(lep[n - 1 - (int)lane], p, pend); wc_add(W, EV_LEP); }
+			for (int i = (int)bt.x - 1; i >= -1; --i) {
+				const uint32_t b = i < 0 ? 4u : rd.at(i);
+				Intv y = p;
+				if (live && b <= 3) { y = extend1<true>(ix, p, (int)b, W); ++my_q; }
+				const bool cand = live && b <= 3 && y.x2 >= min_intv;
+				const uint64_t live_m = __ballot(live), cand_m = __ballot(cand);
+				const int first = __ffsll((long long)live_m) - 1;
+				uint64_t push0 = FTASK_NONE, aux0 = AUX_NONE;
+				if (!((cand_m >> first) & 1ull) && (nm == 0 || i + 1 < last_start)) { // the longest live match stops here (bwt.c:328-336)
+					if ((int)lane == first) push0 = emit_smem(A, r, kind, p, i + 1, pend, aux0);
+					++nm; last_start = i + 1;
+				}
+				const uint64_t before = cand_m & lt_mask;
+				const int prev = before ? 63 - __clzll((long long)before) : (int)lane;
+				const uint64_t px2 = __shfl(y.x2, prev);
+				live = cand && (!before || y.x2 != px2); // bwt.c:337-340
+				if (live) p = y;
+				wave_push<32>(O, push0 != FTASK_NONE, push0, A, aux0);
+				f_long = i;
+				if (__ballot(live) == 0) break;
+			}
+			n = 0; // (skips the streamed form below)
+		}
+		for (int i = (int)bt.x - 1; n > 0 && i >= -1; --i) {
 			uint32_t b = i < 0 ? 4u : rd.at(i);
 			int w = n; bool first_done = false, have_prev = false; uint64_t prev_carry = 0, push0 = FTASK_NONE, aux0 = AUX_NONE;
 			for (int top = n; top > lo; top -= 64) {
@@ -1232,7 +1260,7 @@ __global__ __launch_bounds__(BLOCK, 6) void bwd_win_kernel(const SplitArgs A, co
 
 // the calls with more than 64 LEPs, one wave each; rare, so it runs beside bwd_all_kernel on its own stream
 #ifndef CS_WIDE_BLOCKS
-#define CS_WIDE_BLOCKS 4
+#define CS_WIDE_BLOCKS 6
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(256, CS_WIDE_BLOCKS) void bwd_wide_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctr)

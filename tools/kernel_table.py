@@ -20,7 +20,7 @@ for ln in open(sq):
     f = ln.split()
     if len(f) >= 3:
         sqc.setdefault(f[0], {})[f[1]] = float(f[2])
-WAVES = {"fwd0_kernel": 8, "fwd_kernel": 6, "bwd_win_kernel": 6, "bwd_win0_kernel": 6, "bwd_wide_kernel": 4, "bwd_all_kernel": 5, "r2text_kernel": 5, "r3text_kernel": 5}
+WAVES = {"fwd0_kernel": 8, "fwd_kernel": 6, "bwd_win_kernel": 6, "bwd_win0_kernel": 6, "bwd_wide_kernel": 6, "bwd_all_kernel": 5, "r2text_kernel": 5, "r3text_kernel": 5}
 print("| kernel | dispatches / pass | model bytes / pass | FETCH_SIZE / pass | fetch / model | ms serialised | ms in the overlapped run | fetch at serialised time, of 8 TB/s | VALU share of issue slots | waiting (SQ_WAIT_ANY / wave cycles) |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 tm = tf = 0.0
