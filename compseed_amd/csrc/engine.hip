@@ -720,7 +720,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 	A.lep = e->d_lep.p; A.lep_stride = stride;
 	A.task_ctr = C; A.n_queries = C + 8; A.err = C + 7; A.n_sst_hits = C + 9; A.sst = par->sst_mode; A.sst2 = e->d_sst2.p; A.jump = e->jump_k ? e->d_jump.p : nullptr; A.jump_k = e->jump_k;
 	A.evc = e->d_evc.p;
-	A.fq_cap = fq_cap; A.n_f_next = C + 1; A.n_btasks = C + 13; A.n_text_sweeps = C + 14;
+	A.fq_cap = fq_cap; A.n_f_next = C + 1; A.n_btasks = C + 13; A.n_text_sweeps = C + 14; A.n_r2_quick = C + 11;
 	A.text_sweep = (dis & CS_DISABLE_TEXT_SWEEP) ? 0 : 1;
 	// window scheme for the backward sweeps (smem_split.hpp, bwd_win_run): needs the jump table and jump_k <= min_seed_len <= jump_k + 4
 	A.win = !(dis & CS_DISABLE_WINDOW) && par->sst_mode != 0 && A.jump && A.jump_k <= A.min_seed_len && A.min_seed_len - 1 <= WIN_LANES ? 1 : 0;

@@ -59,6 +59,7 @@ struct SplitArgs {
 	const uint64_t *fq; uint64_t n_f;                 // forward tasks of this launch
 	uint64_t *fq_next; unsigned long long *n_f_next; uint64_t fq_cap;
 	unsigned long long *n_text_sweeps;                // backward sweeps answered from the text (fwd_kernel)
+	unsigned long long *n_r2_quick;                   // re-seeding calls settled by fwd0_kernel itself (counted with r2text_kernel's)
 	const uint64_t *bloom; uint32_t bloom_bits;       // k-mer filter of the text for k = min_seed_len (kmer_filter_*), or null
 	int32_t   win;                                    // window scheme for the backward sweeps (bwd_win_run) is on
 	int32_t   text_sweep;                             // that shortcut is enabled (CS_TEXT_SWEEP, default on)
@@ -92,7 +93,7 @@ __device__ __forceinline__ void push_ftask(const SplitArgs &A, uint64_t t, uint6
 	if (s < A.fq_cap) { A.fq_next[s] = t; if (aux != ~0ull) A.aux_next[s] = aux; } else atomicMax(A.err, 2ull);
 }
 constexpr uint64_t FTASK_NONE = ~0ull; // kind bits = TK_NOP
-constexpr uint64_t AUX_NONE = ~0ull;
+constexpr uint64_t AUX_NONE = ~0ull, POS_NONE = ~0ull;
 // an SMEM of a round-1/2 call: length filter (bwamem.c:232,246); returns the re-seeding call a round-1 SMEM triggers
 // (bwamem.c:241-249) or FTASK_NONE.  aux: for the re-seeding call of a UNIQUE SMEM (min_intv 2), what r2text_kernel needs
 // to find the SMEM in the text: x0 | beg << 37 | parity(beg + end) << 53.
@@ -385,6 +386,35 @@ __global__ void kmer_filter_fill_kernel(const DevIndex ix, int k, uint64_t *bloo
 		atomicOr((unsigned long long *)&bloom[h >> (64u - bits)], (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)));
 	}
 }
+// The re-seeding call of a unique SMEM, the part most calls come to: in sequence that is not repeated, rep[] stays
+// below min_seed_len around the pivot.  If it does at all the min_seed_len offsets up to the pivot (and is never 0), the sweep of
+// r2_by_text ends within them (o + rep[o] <= pivot at the latest at o = pivot - min_seed_len + 1), touches neither end of the SMEM and
+// reports nothing: the call is answered by three or four words of rep[].  0: answered; 1: needs the sweep.  P: text position of the
+// SMEM's first base, len its length, po the pivot's offset in it; nw: words read.
+__device__ __forceinline__ int r2_quick_rep(const DevIndex &ix, uint64_t P, int len, int po, int k, uint32_t &nw)
+{
+	nw = 0;
+	if (po < k || po + k > len || k > 32) return 1;
+	const uint64_t lo = P + (uint64_t)(po - k + 1), hi = P + (uint64_t)po;   // the bytes rep[lo .. hi]
+	const uint64_t *wp = reinterpret_cast<const uint64_t *>(ix.rep) + (lo >> 3);
+	nw = (uint32_t)((hi >> 3) - (lo >> 3)) + 1u;                               // 3..5 aligned words for k <= 32
+	uint64_t wd[5];
+#pragma unroll
+	for (int q = 0; q < 5; ++q) wd[q] = (uint32_t)q < nw ? wp[q] : 0x0101010101010101ull;
+	const uint64_t ones = 0x0101010101010101ull, top = 0x8080808080808080ull;
+	const uint64_t fl = ((lo & 7) ? ~0ull << ((lo & 7) << 3) : ~0ull), fh = ~0ull >> ((7 - (hi & 7)) << 3); // bytes of the first / last word that count
+	uint64_t bad = 0;
+#pragma unroll
+	for (int q = 0; q < 5; ++q) {
+		const uint64_t w = wd[q];
+		uint64_t f = ((((w & ~top) + (uint64_t)(0x80 - k) * ones) | w) & top)    // a byte >= k
+		           | ((w - ones) & ~w & top);                                    // a byte == 0
+		if (q == 0) f &= fl;
+		if ((uint32_t)q + 1u == nw) f &= fh;
+		if ((uint32_t)q < nw) bad |= f;
+	}
+	return bad ? 1 : 0;
+}
 // the call that follows a finished round-1 call at pivot x_cur: next pivot = end of the longest forward match, ambiguous
 // bases skipped.  A round-1 task carries, in the field that holds min_intv for round 2 (round 1 always uses 1), the
 // distance to the previous pivot + 1 when the forward pass ended ON the new pivot (no ambiguous base in between): no
@@ -438,7 +468,6 @@ __global__ __launch_bounds__(BLOCK, 6) void fwd_kernel(const SplitArgs A)
 		ik = set_intv(ix, (int)scode); i = x + 1;
 		return false;
 	};
-
 	for (;;) {
 		uint64_t t_id = 0;
 		bool got = pool_take<256>(P, !active, A.task_ctr, A.n_f, t_id);
@@ -590,7 +619,7 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 	int len = 0, i = 0;
 	Intv ik = {0, 0, 0};
 	PackedReader rd;
-	uint32_t my_q = 0, my_hits = 0;
+	uint32_t my_q = 0, my_hits = 0, my_r2 = 0;
 	WavePool P = {0, 0, false};
 	WaveOut O = {0, 0};
 	WaveCtrT<COUNT> W;
@@ -618,11 +647,12 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
 		if (active) {
 			bool fin = false;
+			uint64_t fpos = POS_NONE; // text position of the read's first base, where the match ended in text mode
 			if (textm) { // as in fwd_kernel: the unique match against the 2-bit text, cursor in ik.x1
 				uint64_t tpos = ik.x1;
 				fin = text_step(ix, rd, i, tpos, my_q, my_hits, W);
 				ik.x1 = tpos;
-				if (fin) { ik.x1 = isa_direct(ix, ix.seq_len - tpos); wc_add(W, EV_ISA); }
+				if (fin) { fpos = tpos - (uint64_t)i; ik.x1 = isa_direct(ix, ix.seq_len - tpos); wc_add(W, EV_ISA); }
 			} else {
 				uint32_t b = i < len ? rd.at(i) : 4u;
 				if (b > 3) fin = true;
@@ -642,6 +672,11 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 			}
 			if (fin) { // the call's only SMEM is its longest forward match (bwt.c:325 starts the sweep at -1)
 				push0 = emit_smem(A, r, TK_ROUND1, ik, 0, (uint32_t)i, aux0);
+				if (push0 != FTASK_NONE && aux0 != AUX_NONE && fpos != POS_NONE && ix.rep) { // its re-seeding call, if rep[] settles it right here
+					uint32_t nw; const int pv = i >> 1;                                        // (emit_smem: pivot = (beg + end) / 2, beg = 0)
+					if (A.min_seed_len >= 2 && fpos + (uint64_t)i <= ix.seq_len && pv <= 4096 && r2_quick_rep(ix, fpos, i, pv, A.min_seed_len, nw) == 0) { push0 = FTASK_NONE; ++my_r2; }
+					wc_add(W, EV_REP, nw);
+				}
 				push1 = chain_round1(rd, r, len, i, 0);
 				active = false;
 			}
@@ -654,6 +689,7 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 	wave_push_finish(O, A);
 	atomicAdd(A.n_queries, (unsigned long long)my_q);
 	if (my_hits) atomicAdd(A.n_sst_hits, (unsigned long long)my_hits);
+	if (my_r2) atomicAdd(A.n_r2_quick, (unsigned long long)my_r2);
 	wc_flush(W, A.evc, KID_FWD0);
 }
 
@@ -1335,10 +1371,7 @@ __device__ __forceinline__ bool text_interval(const DevIndex &ix, uint64_t pos, 
 	out.x0 = lo; out.x1 = lo2; out.x2 = hi - lo + 1;
 	return true;
 }
-// What most calls come to: in sequence that is not repeated, rep[] stays below min_seed_len around the pivot.  If it does at
-// all the min_seed_len offsets up to the pivot (and is never 0), the sweep below ends within them (o + rep[o] <= pivot at the
-// latest at o = pivot - min_seed_len + 1), touches neither end of the SMEM and reports nothing: the call is answered by three
-// or four words of rep[].  0: answered; 1: needs the sweep; 2: the text cannot tell.  P: text position of the SMEM's first base.
+// (r2_quick_rep, further up, is the test on rep[] itself: fwd0_kernel asks it too.)  0: answered; 1: needs the sweep; 2: the text cannot tell.
 __device__ __forceinline__ int r2_quick(const SplitArgs &A, uint64_t x0, int beg, int end, int pivot, uint64_t &P, LaneCtr &C)
 {
 	const DevIndex &ix = A.ix;
@@ -1347,27 +1380,10 @@ __device__ __forceinline__ int r2_quick(const SplitArgs &A, uint64_t x0, int beg
 	P = sa_direct(ix, x0);
 	++C.sa;
 	if (P >= ix.seq_len || P + (uint64_t)len > ix.seq_len) return 2; // (an SMEM lies inside the text)
-	if (po < k || po + k > len || k > 32) return 1;
-	const uint64_t lo = P + (uint64_t)(po - k + 1), hi = P + (uint64_t)po;   // the bytes rep[lo .. hi]
-	const uint64_t *wp = reinterpret_cast<const uint64_t *>(ix.rep) + (lo >> 3);
-	const uint32_t nw = (uint32_t)((hi >> 3) - (lo >> 3)) + 1u;                // 3..5 aligned words for k <= 32
-	uint64_t wd[5];
-#pragma unroll
-	for (int q = 0; q < 5; ++q) wd[q] = (uint32_t)q < nw ? wp[q] : 0x0101010101010101ull;
+	uint32_t nw = 0;
+	const int q = r2_quick_rep(ix, P, len, po, k, nw);
 	C.rep += nw;
-	const uint64_t ones = 0x0101010101010101ull, top = 0x8080808080808080ull;
-	const uint64_t fl = ((lo & 7) ? ~0ull << ((lo & 7) << 3) : ~0ull), fh = ~0ull >> ((7 - (hi & 7)) << 3); // bytes of the first / last word that count
-	uint64_t bad = 0;
-#pragma unroll
-	for (int q = 0; q < 5; ++q) {
-		const uint64_t w = wd[q];
-		uint64_t f = ((((w & ~top) + (uint64_t)(0x80 - k) * ones) | w) & top)    // a byte >= k
-		           | ((w - ones) & ~w & top);                                    // a byte == 0
-		if (q == 0) f &= fl;
-		if ((uint32_t)q + 1u == nw) f &= fh;
-		if ((uint32_t)q < nw) bad |= f;
-	}
-	return bad ? 1 : 0;
+	return q;
 }
 __device__ __forceinline__ bool r2_by_text(const SplitArgs &A, uint32_t r, uint64_t P, int beg, int end, int pivot, LaneCtr &C)
 {
