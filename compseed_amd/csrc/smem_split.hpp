@@ -673,7 +673,7 @@ __global__ __launch_bounds__(BLOCK, 8) void fwd0_kernel(const SplitArgs A, uint6
 			if (fin) { // the call's only SMEM is its longest forward match (bwt.c:325 starts the sweep at -1)
 				push0 = emit_smem(A, r, TK_ROUND1, ik, 0, (uint32_t)i, aux0);
 				if (push0 != FTASK_NONE && aux0 != AUX_NONE && fpos != POS_NONE && ix.rep) { // its re-seeding call, if rep[] settles it right here
-					uint32_t nw; const int pv = i >> 1;                                        // (emit_smem: pivot = (beg + end) / 2, beg = 0)
+					uint32_t nw = 0; const int pv = i >> 1;                                    // (emit_smem: pivot = (beg + end) / 2, beg = 0)
 					if (A.min_seed_len >= 2 && fpos + (uint64_t)i <= ix.seq_len && pv <= 4096 && r2_quick_rep(ix, fpos, i, pv, A.min_seed_len, nw) == 0) { push0 = FTASK_NONE; ++my_r2; }
 					wc_add(W, EV_REP, nw);
 				}
