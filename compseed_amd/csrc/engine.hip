@@ -513,14 +513,6 @@ static int scan_counts(cs_engine *e, const uint32_t *cnt, uint64_t *off, size_t 
 	HIP_TRY(rocprim::exclusive_scan(e->d_tmp.p, tmp, in, off, init, n + 1, rocprim::plus<uint64_t>(), e->stream));
 	return CS_OK;
 }
-static int scan_u64(cs_engine *e, const uint64_t *cnt, uint64_t *off, size_t n)
-{
-	size_t tmp = 0;
-	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, cnt, off, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), e->stream));
-	CS_TRY(e->d_tmp.reserve(tmp + 16));
-	HIP_TRY(rocprim::exclusive_scan(e->d_tmp.p, tmp, cnt, off, (uint64_t)0, n + 1, rocprim::plus<uint64_t>(), e->stream));
-	return CS_OK;
-}
 
 __global__ void max_len_kernel(const uint64_t *off, int64_t n, uint64_t n_bases, unsigned long long *out_max, unsigned long long *bad)
 {
