@@ -186,6 +186,17 @@ __global__ void jump_fill_kernel(const DevIndex ix, int k, uint4 *table)
 template <bool RAW>
 __global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64_t n_reads, uint64_t n_bases, uint4 *rec)
 {
+	// letters -> codes through a 256-byte table in LDS (((c >> 1) ^ (c >> 2)) & 3 for A C G T in either case, the codes 0..3 as they
+	// are, 4 for everything else): one LDS read per base instead of a dozen instructions
+	__shared__ uint8_t lut[256];
+	if (RAW) {
+		for (uint32_t c = threadIdx.x; c < 256u; c += blockDim.x) {
+			const uint32_t t = (c & 0xdfu) - 0x41u;
+			const bool letter = t < 20u && ((0x80045u >> t) & 1u);
+			lut[c] = (uint8_t)(c < 4u ? c : letter ? ((c >> 1) ^ (c >> 2)) & 3u : 4u);
+		}
+		__syncthreads();
+	}
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = ((uint64_t)gridDim.x * blockDim.x) >> 3;
 	for (uint64_t r = gid >> 3; r < (uint64_t)n_reads; r += gstride) { // eight lanes per read, a record each
 		const uint64_t rb = off[r], re = off[r + 1], len = re - rb;
@@ -203,15 +214,10 @@ __global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
 					uint64_t b8 = sh ? (v[q] >> sh) | (v[q + 1] << (64u - sh)) : v[q]; // bases 8q .. 8q+7, a byte each
-					if (RAW) { // letters -> codes: ((c >> 1) ^ (c >> 2)) & 3 for A C G T in either case, 4 for everything else but the codes 0..3
+					if (RAW) {
 						uint64_t c8 = 0;
 #pragma unroll
-						for (int z = 0; z < 8; ++z) {
-							const uint32_t c = (uint32_t)(b8 >> (8 * z)) & 0xffu, t = (c & 0xdfu) - 0x41u;
-							const bool letter = t < 20u && ((0x80045u >> t) & 1u);
-							const uint32_t code = c < 4u ? c : letter ? ((c >> 1) ^ (c >> 2)) & 3u : 4u;
-							c8 |= (uint64_t)code << (8 * z);
-						}
+						for (int z = 0; z < 8; ++z) c8 |= (uint64_t)lut[(uint32_t)(b8 >> (8 * z)) & 0xffu] << (8 * z);
 						b8 = c8;
 					}
 					bad |= (uint32_t)((((b8 >> 2) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * q);
