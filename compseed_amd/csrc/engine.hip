@@ -134,7 +134,7 @@ struct cs_engine {
 	DevBuf<unsigned long long> d_ctr; // [0] task counter, [1] queries, [2] overflow count, [3] max len
 	DevBuf<uint8_t> d_tmp, d_tmp2;
 	// results (device)
-	DevBuf<uint64_t> d_mem_off, d_seed_off, d_seed_of_mem; DevBuf<OutMem> d_mems; DevBuf<OutSeed> d_seeds;
+	DevBuf<uint64_t> d_mem_off, d_seed_off, d_seed_of_mem; DevBuf<OutMem> d_mems; DevBuf<uint64_t> d_salcnt; DevBuf<OutSeed> d_seeds; // d_salcnt: SA slots per mem, written by the sort that makes d_mems
 	// results (pinned host)
 	PinBuf<uint64_t> h_mem_off, h_seed_off; PinBuf<OutMem> h_mems; PinBuf<OutSeed> h_seeds;
 	PinBuf<unsigned long long> h_ctr;
@@ -445,7 +445,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_pending.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_seqp.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
-	e->d_mems.release(); e->d_seeds.release();
+	e->d_mems.release(); e->d_salcnt.release(); e->d_seeds.release();
 	e->d_fqA.release(); e->d_fqB.release(); e->d_fqR.release(); e->d_sst2.release(); e->d_jump.release(); e->d_bq.release(); e->d_lep.release(); e->d_ovfrec.release();
 	e->d_evc.release(); e->d_sel.release(); e->d_sel_moff.release(); e->d_sel_soff.release(); e->d_sel_mems.release(); e->d_sel_seeds.release();
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
@@ -907,7 +907,8 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	CS_TRY(e->d_out.reserve((size_t)per_launch * cap));
 	CS_TRY(e->d_cnt.reserve((size_t)per_launch + 1));
 	CS_TRY(e->d_ovf.reserve((size_t)per_launch));
-	CS_TRY(e->d_mems.reserve((size_t)n_reads * 10 + 1024));
+	CS_TRY(e->d_mems.reserve((size_t)n_reads * 10 + 1024)); CS_TRY(e->d_salcnt.reserve((size_t)n_reads * 10 + 1024));
+	bool salcnt_ok = true; // every mem's slot count was written by a sort_compact*_kernel of the split path
 
 	uint64_t total_mems = 0;
 	for (int64_t b0 = 0; b0 < n_reads; b0 += per_launch) {
@@ -930,14 +931,15 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 				CS_TRY(fetch_words(e->h_ctr, 0, e->d_mem_off.p + b0 + nb, 1, s));
 				HIP_TRY(hipStreamSynchronize(s));
 				uint64_t new_total = e->h_ctr.p[0];
-				CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
+				CS_TRY(e->d_mems.reserve((size_t)new_total + 16, true, s, (size_t)total_mems)); CS_TRY(e->d_salcnt.reserve((size_t)new_total + 16, true, s, (size_t)total_mems));
+				const uint32_t mo = (uint32_t)par->max_occ;
 				int fast16 = cap >= 16 ? 1 : 0;
 				if (fast16) hipLaunchKernelGGL(sort_compact16_kernel, dim3(grid_for(nb * 16, 256)), dim3(256), 0, s, e->d_out.p, e->d_cnt.p, cap,
-				                               e->d_mem_off.p + b0, nb, e->d_mems.p);
+				                               e->d_mem_off.p + b0, nb, e->d_mems.p, e->d_salcnt.p, mo);
 				if (fast16) hipLaunchKernelGGL(sort_compact_wave_kernel, dim3(grid_for(nb, 256)), dim3(256), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
-				                               e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p);
+				                               e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p, e->d_salcnt.p, mo);
 				else hipLaunchKernelGGL(sort_compact2_kernel, dim3(grid_for(nb, 128)), dim3(128), 0, s, e->d_out.p, e->d_cnt.p, cap, e->d_ovfrec.p,
-				                        e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p, 0);
+				                        e->d_okey2.p, e->d_oidx2.p, n_ovf2, e->d_mem_off.p + b0, nb, e->d_mems.p, 0, e->d_salcnt.p, mo);
 				HIP_TRY(hipGetLastError());
 				total_mems = new_total;
 				continue;
@@ -945,6 +947,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 			// rc == 1: a task queue overflowed -- redo this sub-batch with the fused kernel
 		}
 		CS_TRY(make_nt4()); // (the fused kernel reads a byte per base)
+		salcnt_ok = false;
 		HIP_TRY(hipMemsetAsync(e->d_cnt.p + nb, 0, sizeof(uint32_t), s));
 		CS_TRY(launch_smem(e, par, d_off + b0, nullptr, nb, e->d_out.p, e->d_cnt.p, cap, max_len));
 		HIP_TRY(hipMemsetAsync(e->d_ctr.p + 2, 0, sizeof(unsigned long long), s));
@@ -1003,9 +1006,10 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 		DevBuf<uint64_t> &som = e->d_seed_of_mem;
 		CS_TRY(e->d_tmp.reserve(((size_t)total_mems + 2) * 8 + 1024));
 		uint64_t *cnt64 = (uint64_t *)e->d_tmp.p;
+		if (salcnt_ok && e->smem_mode == 1) { CS_TRY(e->d_salcnt.reserve((size_t)total_mems + 16, true, s, (size_t)total_mems)); cnt64 = e->d_salcnt.p; } // (counted while sorting)
 		HIP_TRY(hipEventRecord(e->ev[0], s));
 		HIP_TRY(hipMemsetAsync(cnt64 + total_mems, 0, 8, s));
-		if (total_mems)
+		if (total_mems && cnt64 != e->d_salcnt.p)
 			hipLaunchKernelGGL(sal_count_kernel, dim3(grid_for((int64_t)total_mems, 256)), dim3(256), 0, s, e->d_mems.p, total_mems,
 			                   (uint32_t)par->max_occ, cnt64);
 		{ // scan needs its own temp storage: keep the counts where they are and scan with a second buffer

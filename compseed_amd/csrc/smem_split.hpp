@@ -1734,14 +1734,15 @@ __device__ __forceinline__ const OutMem &mem_at(const OutMem *src, uint32_t cap,
 	return a < cap ? src[a] : ovf[ovf_idx[olo + (a - cap)]].m;
 }
 __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uint32_t cap, const OvfRec *ovf, const uint32_t *ovf_key,
-                                     const uint32_t *ovf_idx, uint64_t n_ovf, const uint64_t *mem_off, int64_t n_reads, OutMem *mems, int skip_small)
+                                     const uint32_t *ovf_idx, uint64_t n_ovf, const uint64_t *mem_off, int64_t n_reads, OutMem *mems, int skip_small,
+                                     uint64_t *salcnt, uint32_t max_occ)
 {
 	int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	uint32_t n = cnt[r];
 	if (skip_small && n <= 64 && n <= cap) return; // done by sort_compact16_kernel
 	const OutMem *src = raw + (size_t)r * cap;
-	OutMem *dst = mems + mem_off[r];
+	OutMem *dst = mems + mem_off[r]; uint64_t *dsc = salcnt + mem_off[r]; // (the SA slots each mem will ask for: comp_seed.cpp:2313-2325)
 	if (n <= 16 && n <= cap) { // keys in registers, ranks by 16 x 16 compares, no re-reads
 		uint64_t k[16];
 #pragma unroll
@@ -1752,7 +1753,7 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 				uint32_t rank = 0;
 #pragma unroll
 				for (int b = 0; b < 16; ++b) rank += (k[b] < k[a]) || (k[b] == k[a] && b < a); // padding keys are never smaller
-				dst[rank] = src[a];
+				dst[rank] = src[a]; dsc[rank] = src[a].x2 < max_occ ? src[a].x2 : max_occ;
 			}
 		}
 		return;
@@ -1767,7 +1768,7 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 		OutMem ma = mem_at(src, cap, ovf, ovf_idx, olo, a);
 		uint32_t rank = 0;
 		for (uint32_t b = 0; b < n; ++b) { uint64_t kb = mem_at(src, cap, ovf, ovf_idx, olo, b).info; rank += (kb < ma.info) || (kb == ma.info && b < a); }
-		dst[rank] = ma;
+		dst[rank] = ma; dsc[rank] = ma.x2 < max_occ ? ma.x2 : max_occ;
 	}
 }
 // The reads sort_compact16_kernel leaves out (more than 64 mems, or mems beyond `cap`: tandem arrays, repeats): one WAVE per
@@ -1775,7 +1776,8 @@ __global__ void sort_compact2_kernel(const OutMem *raw, const uint32_t *cnt, uin
 // owns mems j, j+64, ...; the keys of 64 mems at a time sit in registers and travel by shuffle.  (One lane per read made
 // this kernel as slow as its slowest read: 5 ms for a handful of reads with hundreds of mems.)
 __global__ __launch_bounds__(256) void sort_compact_wave_kernel(const OutMem *raw, const uint32_t *cnt, uint32_t cap, const OvfRec *ovf, const uint32_t *ovf_key,
-                                                                const uint32_t *ovf_idx, uint64_t n_ovf, const uint64_t *mem_off, int64_t n_reads, OutMem *mems)
+                                                                const uint32_t *ovf_idx, uint64_t n_ovf, const uint64_t *mem_off, int64_t n_reads, OutMem *mems,
+                                                                uint64_t *salcnt, uint32_t max_occ)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1806,7 +1808,7 @@ __global__ __launch_bounds__(256) void sort_compact_wave_kernel(const OutMem *ra
 					rank += (kj < ma.info) || (kj == ma.info && b0 + (uint32_t)j < a);
 				}
 			}
-			if (a < n) dst[rank] = ma;
+			if (a < n) { dst[rank] = ma; salcnt[mem_off[r] + rank] = ma.x2 < max_occ ? ma.x2 : max_occ; }
 		}
 	}
 }
@@ -1816,7 +1818,7 @@ __global__ __launch_bounds__(256) void sort_compact_wave_kernel(const OutMem *ra
 // keys travel by shuffle, and every lane writes its mems at their ranks.  Reads with more than 64 mems, or whose mems
 // spilled beyond `cap`, are left to sort_compact2_kernel (launched over the same range with skip_upto = 64).
 __global__ __launch_bounds__(256) void sort_compact16_kernel(const OutMem *raw, const uint32_t *cnt, uint32_t cap, const uint64_t *mem_off,
-                                                             int64_t n_reads, OutMem *mems)
+                                                             int64_t n_reads, OutMem *mems, uint64_t *salcnt, uint32_t max_occ)
 {
 	const uint32_t lane = threadIdx.x & 63u, a = lane & 15u, gbase = lane & ~15u;
 	int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -1841,9 +1843,9 @@ __global__ __launch_bounds__(256) void sort_compact16_kernel(const OutMem *raw, 
 		}
 	}
 	if (n) {
-		OutMem *dst = mems + mem_off[r];
+		OutMem *dst = mems + mem_off[r]; uint64_t *dsc = salcnt + mem_off[r];
 #pragma unroll
-		for (int s = 0; s < 4; ++s) if (a + 16u * s < n) dst[rank[s]] = m[s];
+		for (int s = 0; s < 4; ++s) if (a + 16u * s < n) { dst[rank[s]] = m[s]; dsc[rank[s]] = m[s].x2 < max_occ ? m[s].x2 : max_occ; }
 	}
 }
 
