@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- reads/sec of the SMEM seeding hot path on N MI355X (one process per GPU).
 
-A "step" is one pass of the hot path (ASCII->nt4, 3-round SMEM collection, sort, SAL) over one batch of synthetic
+A "step" is one pass of the hot path (reads packed 32 bases per record, 3-round SMEM collection, sort, SAL) over one batch of synthetic
 150-bp reordered reads that is already resident in HBM; results stay in HBM.  Every rank holds a replica of the
 index and its own contiguous share of the read run (weak scaling, no data-path collective: the path shards by
 reads).  Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the roofline and cpu_baseline definitions.
@@ -16,7 +16,8 @@ What the line holds besides the contract's fields:
   roofline        byte model of THIS implementation (bytes the kernels request from the index-side arrays, counted on the
                   device by the counting instantiations in one extra pass) over the live HIP-event time of the SMEM stage;
                   `traffic` = FETCH_SIZE of the same stage from a rocprofv3 --pmc child run of this very script (N = 1)
-  cpu_baseline    the oracle (CPU port) timed on this box's host cores on a bounded sample
+  cpu_baseline    the real reference (oracle/_ref, kind "reference") or, without it, the oracle (CPU port), timed on this box's host
+                  cores on a bounded sample
   pcie_inclusive  the host-buffer boundary call (H2D of reads, D2H of results), SURVEY 8(d)'s metric; never `value`
 """
 import argparse
