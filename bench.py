@@ -69,6 +69,14 @@ def parse_args():
                     help="live: HBM bytes of the SMEM stage from a rocprofv3 --pmc FETCH_SIZE child run of this script (N = 1 only)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: the profiled child of --traffic live
     ap.add_argument("--lib", default="", help="alternative build of libcompseed_amd.so (A/B experiments)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N > 1 path: nccl (= RCCL over xGMI, the default) or gloo (barrier / max / sum and the "
+                         "collectives of --index-broadcast / --ingest-rank0 on CPU tensors staged from the engine's device memory: what lets the "
+                         "whole N > 1 code path run with several ranks on ONE GPU, tests/test_gpu_multirank.py)")
+    ap.add_argument("--side-workloads", default="repeat50",
+                    help="comma-separated workload profiles measured after the headline in a child run of this script (N = 1 only; '' = none): "
+                         "reported under `workloads`, never part of `value`")
+    ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)  # internal: a child run for `workloads`
     ap.add_argument("--index-broadcast", action="store_true",
                     help="N > 1: rank 0 builds the index and broadcasts it over RCCL instead of every rank building its own replica")
     ap.add_argument("--ingest-rank0", action="store_true",
@@ -155,6 +163,29 @@ def pmc_traffic(args):
     return out
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU bandwidth quota where one is set (a GPU box
+    hands each GPU a share of the host's cores that way; threads beyond the quota are throttled, not run).  Returns (cpus, source)."""
+    n = len(os.sched_getaffinity(0))
+    src = "affinity mask"
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse is None:
+                q = float(txt)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                quota = None if q <= 0 else q / per
+            else:
+                quota = parse(txt)
+            if quota is not None and quota > 0 and quota < n:
+                n, src = max(1, int(quota + 0.5)), "cgroup quota (%s)" % path
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return n, src
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -178,13 +209,17 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the seeding engine has no CPU path")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():    # more ranks than GPUs (the one-GPU rehearsal of the N > 1 path): share the devices
+        log("LOCAL_RANK %d on a box with %d GPU(s): using device %d" % (local, torch.cuda.device_count(), local % torch.cuda.device_count()))
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import compseed_amd as ca
     from compseed_amd.sharding import Dist
     import synth
-    D = Dist("nccl")                      # RCCL; used for the barrier and the max-over-ranks clock only
+    D = Dist(args.dist_backend, local=local)   # RCCL by default; used for the barrier and the max-over-ranks clock only
     rank, world = D.rank, D.world
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
     if world != args.gpus and world > 1:
         log("WORLD_SIZE %d != --gpus %d, using WORLD_SIZE" % (world, args.gpus))
 
@@ -198,7 +233,7 @@ def main():
     t1 = time.time()
     torch.cuda.empty_cache()
     from compseed_amd.sharding import Collectives, device_tensor_view
-    coll = Collectives(D, dev)
+    coll = Collectives(D, cdev)
     if args.index_broadcast and world > 1:  # one build, then the arrays travel over xGMI
         arrays = None
         if rank == 0:
@@ -292,11 +327,16 @@ def main():
     if not args.no_sal:
         ok = ok and np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"])
     all_ok = D.sum_over_ranks(0.0 if ok else 1.0) == 0.0
+    # every rank's share of the read run (genome window its reads were sampled from, first / last sampled read as a checksum of the share)
+    shares = D.gather_objects({"rank": rank, "device": local, "genome_window": [rank / world, (rank + 1) / world], "reads": args.reads,
+                               "first_read_crc": int(np.frombuffer(hb[:args.read_len].tobytes(), dtype=np.uint8).astype(np.uint64).dot(np.arange(1, args.read_len + 1, dtype=np.uint64))),
+                               "bit_exact_vs_oracle": bool(ok)})
     if not ok:
         log("PARITY FAILURE on rank %d against the oracle (strided sample of %d reads)" % (rank, nchk))
 
     if rank == 0:
-        out["parity"] = {"checked_reads_per_rank": int(nchk), "stride": int(stride), "ranks_checked": world, "bit_exact_vs_oracle": bool(all_ok)}
+        out["parity"] = {"checked_reads_per_rank": int(nchk), "stride": int(stride), "ranks_checked": len(shares), "bit_exact_vs_oracle": bool(all_ok),
+                         "rank_shares": shares, "dist_backend": args.dist_backend}
         ws = want["stats"]
         # ---- roofline.  Stage = every launch of one pass of the SMEM collection (fwd0 / fwd / bwd_* / r2text / r3text [/ tail]);
         # its time per pass is measured live with HIP events on the engine's stream over the timed region (seed_kernel_ms).
@@ -395,6 +435,21 @@ def main():
                                                 "sample": "first %d reads of rank 0's batch; the reference's own seeding + SAL code (oracle/_ref/ref_dump --time: "
                                                           "collect_mem_with_sst / tem_forward_sst / bwt_sa, SSTs per 512 reads), %d threads, %.1f s; port_value = "
                                                           "oracle/cs_oracle.c on the same sample" % (ncpu, cores, rj["seconds"])})
+                    # the same on ALL usable host cores of the box ("-t = all host cores"; main.cpp:203-214 prints per-thread sums):
+                    # a sample sized for ~10 s at the rate the 16-thread run predicts
+                    usable, usable_src = cpu_quota()
+                    out["cpu_baseline"]["host_cpus_usable"] = {"cpus": usable, "source": usable_src}
+                    if usable > cores:
+                        n_all = int(min(args.reads, max(ncpu, rj["reads_per_s"] * (usable / cores) * 0.6 * min(10.0, args.cpu_seconds))))
+                        ca_b = bases[: n_all * args.read_len].cpu().numpy()
+                        with open(os.path.join(td, "reads_all.txt"), "wb") as f:
+                            f.write(np.concatenate([ca_b.reshape(n_all, args.read_len), np.full((n_all, 1), 10, np.uint8)], axis=1).tobytes())
+                        del ca_b
+                        ra = subprocess.run([ref_bin, os.path.join(td, "idx"), os.path.join(td, "reads_all.txt"), "/dev/null", "--time", str(usable),
+                                             "-y", str(args.y), "-c", str(args.c)], capture_output=True, text=True, timeout=120)
+                        rja = json.loads(ra.stdout.strip().splitlines()[-1])
+                        out["cpu_baseline"]["all_cores"] = {"value": rja["reads_per_s"], "unit": "reads/s", "cores": usable, "kind": "reference",
+                                                            "sample": "first %d reads of rank 0's batch, ref_dump --time %d, %.1f s" % (n_all, usable, rja["seconds"])}
                 except Exception as ex:  # noqa: BLE001
                     log("reference CPU baseline not available: %r" % (ex,))
                 finally:
@@ -458,6 +513,10 @@ def main():
                         "out: upload, seeding, download and the host-side expansion of the packed results overlapped over sub-batches); packed_reads_per_s = "
                         "cs_engine_seed_batch_packed (the 16-byte / 8-byte form a consumer unpacks while it copies per read anyway); pipelined_packed_reads_per_s "
                         "= a stream of such batches with two in flight (cs_engine_submit / cs_engine_collect_packed), per batch; never `value`"}
+            # SURVEY 8(d) defines the metric "incl. H2D/D2H of reads/results": these are the conforming figures, under a key that says so
+            # (`value` is the device-resident rate the bench contract asks for)
+            out["reads_per_s_incl_pcie"] = {"pipelined_two_batches_in_flight": args.reads / dt_s, "one_blocking_call_packed": args.reads / dt_p,
+                                            "one_blocking_call_expanded": args.reads / dt_x, "bit_exact_vs_oracle": bool(ok_x and ok_p)}
             if not (ok_x and ok_p):
                 all_ok = False
             del hb_pin, ho_all, hb_page
@@ -477,10 +536,12 @@ def main():
             big = (big_b, big_o)
         D.barrier(); t_a = time.perf_counter()
         mb, mo = coll.scatter_reads(big[0] if big else None, big[1] if big else None)
+        if args.dist_backend != "nccl":   # gloo moved CPU tensors: this rank's range goes back to its GPU
+            mb, mo = mb.to(dev), mo.to(dev)
         torch.cuda.synchronize(); D.barrier(); t_b = time.perf_counter()
         r2 = eng.seed_batch_device(mb.data_ptr(), mo.data_ptr(), mo.numel() - 1, mb.numel(), par)
         D.barrier(); t_c = time.perf_counter()
-        v64 = lambda ptr, nbytes: device_tensor_view(ptr, nbytes, dev).view(torch.int64)
+        v64 = lambda ptr, nbytes: device_tensor_view(ptr, nbytes, dev).view(torch.int64).to(cdev)   # (no copy under nccl)
         sal_on = not args.no_sal
         g_ = coll.gather_results(v64(r2.ptr["mem_off"], (r2.n_reads + 1) * 8), v64(r2.ptr["mems"], r2.n_mems * 32),
                                v64(r2.ptr["seed_off"], (r2.n_reads + 1) * 8) if sal_on else None, v64(r2.ptr["seeds"], r2.n_seeds * 16) if sal_on else None)
@@ -490,6 +551,10 @@ def main():
             ok_g = int(g_["mem_off"][-1]) * 4 == g_["mems"].numel() and g_["mem_off"].numel() == tot + 1
             # rank 0's own share must come back unchanged at the front of the gathered arrays
             ok_g = ok_g and bool(torch.equal(g_["mems"][: r2.n_mems * 4], v64(r2.ptr["mems"], r2.n_mems * 32)))
+            # ... and every other rank's share is the same reads again, so its mems must equal rank 0's (positions and all)
+            for g in range(1, world):
+                m0, m1 = int(g_["mem_off"][g * args.reads]), int(g_["mem_off"][(g + 1) * args.reads])
+                ok_g = ok_g and (m1 - m0) == r2.n_mems and bool(torch.equal(g_["mems"][m0 * 4: m1 * 4], g_["mems"][: r2.n_mems * 4]))
             out_ing = {"reads": tot, "reads_per_s": tot / (t_d - t_a), "scatter_ms": 1e3 * (t_b - t_a), "seed_ms": 1e3 * (t_c - t_b), "gather_ms": 1e3 * (t_d - t_c),
                        "scatter_bytes": int(big[0].numel() + big[1].numel() * 8), "gather_bytes": int(sum(t.numel() for t in g_.values() if t is not None) * 8),
                        "consistent": bool(ok_g),
@@ -497,11 +562,40 @@ def main():
                                "to rank 0, all over torch.distributed / RCCL, nothing overlapped"}
             out["ingest_rank0"] = out_ing
         del big, g_
+    oidx.close()
+    eng.close(); ix.close()
+    side = [w for w in args.side_workloads.split(",") if w and w != args.profile]
+    if rank == 0 and world == 1 and side and not args.side_child and not args.pmc_child:
+        # ---- the same measurement on other workload profiles (tools/synth.py), outside the headline: a child run of this script per
+        # profile once this process has given its HBM back (index + derived arrays are ~140 GB per engine).  Same parity gate.
+        del bases, off
+        torch.cuda.empty_cache()
+        out["workloads"] = {}
+        for w in side:
+            cmd = [sys.executable, os.path.abspath(__file__), "--side-child", "--profile", w, "--steps", "3", "--warmup", "1", "--traffic", "none",
+                   "--cpu-seconds", "0", "--no-host-io", "--genome-mbp", str(args.genome_mbp), "--reads", str(args.reads), "--read-len", str(args.read_len),
+                   "--check-reads", str(args.check_reads), "-k", str(args.k), "-r", str(args.r), "-y", str(args.y), "-c", str(args.c), "-s", str(args.s)]
+            if args.lib:
+                cmd += ["--lib", args.lib]
+            for o in args.opt:
+                cmd += ["--opt", o]
+            try:
+                rr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                cj = json.loads(rr.stdout.strip().splitlines()[-1])
+                out["workloads"][w] = {"reads_per_s": cj["value"], "ms_per_step": cj["ms_per_step"], "stage_ms": cj["roofline"]["kernel_ms_per_launch"],
+                                       "parity": cj["parity"]["bit_exact_vs_oracle"], "checked_reads": cj["parity"]["checked_reads_per_rank"],
+                                       "model_bytes_per_read": cj["roofline"]["model_bytes_per_read"], "roofline_frac": cj["roofline"]["frac"],
+                                       "answered_without_fm_index": cj["roofline"]["answered_without_fm_index"], "workload": cj["config"]["workload"]}
+                if not cj["parity"]["bit_exact_vs_oracle"]:
+                    all_ok = False
+                    out["value"] = None
+                    out["error"] = "workload %s: results differ from the oracle" % w
+            except Exception as ex:  # noqa: BLE001
+                log("side workload %s failed: %r" % (w, ex))
+                out["workloads"][w] = {"error": repr(ex)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)   # the ONE line
-    oidx.close()
     D.close()
-    eng.close(); ix.close()
     return 0 if all_ok else 1
 
 

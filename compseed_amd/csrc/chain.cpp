@@ -17,9 +17,10 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
-struct cs_refseq_view { int64_t l_pac; std::vector<int64_t> offset; std::vector<int32_t> len; };
+struct cs_refseq_view { int64_t l_pac; std::vector<int64_t> offset; std::vector<int32_t> len; std::vector<uint8_t> is_alt; };
 
 struct cs_chainer { cs_refseq_view ref; std::vector<cs_chain_t> chains; std::vector<uint64_t> chain_off, cseed_off; std::vector<cs_seed_t> cseeds; };
 
@@ -106,40 +107,40 @@ struct Tree { // node 0 is the root until it splits; nodes live in a vector that
 
 struct Chain { int64_t pos; int32_t rid; std::vector<cs_seed_t> seeds; };
 
-inline int pos2rid(const cs_refseq_view &R, int64_t pos_f) // bns_pos2rid, bntseq.c:346-362
+// contig of a forward-strand position (bns_pos2rid, bntseq.c:346-362): the last contig that starts at or before it
+inline int contig_of(const cs_refseq_view &R, int64_t fwd_pos)
 {
-	if (pos_f >= R.l_pac) return -1;
-	const int n = (int)R.offset.size();
-	int left = 0, mid = 0, right = n;
-	while (left < right) {
-		mid = (left + right) >> 1;
-		if (pos_f >= R.offset[mid]) {
-			if (mid == n - 1) break;
-			if (pos_f < R.offset[mid + 1]) break;
-			left = mid + 1;
-		} else right = mid;
-	}
-	return mid;
+	if (fwd_pos >= R.l_pac) return -1;
+	return (int)(std::upper_bound(R.offset.begin(), R.offset.end(), fwd_pos) - R.offset.begin()) - 1;
 }
-inline int64_t depos(const cs_refseq_view &R, int64_t pos) { return pos >= R.l_pac ? (R.l_pac << 1) - 1 - pos : pos; } // bns_depos, bntseq.h:87
-inline int intv2rid(const cs_refseq_view &R, int64_t rb, int64_t re) // bns_intv2rid, bntseq.c:370-378
+// contig of a seed [rb, re) in the doubled coordinate system (bns_intv2rid, bntseq.c:370-378): positions on the reverse strand are
+// mirrored back first (bns_depos, bntseq.h:87); -2 = bridges the forward-reverse boundary, -1 = bridges two contigs
+inline int contig_of_seed(const cs_refseq_view &R, int64_t rb, int64_t re)
 {
-	if (rb < R.l_pac && re > R.l_pac) return -2;
-	const int rid_b = pos2rid(R, depos(R, rb));
-	const int rid_e = rb < re ? pos2rid(R, depos(R, re - 1)) : rid_b;
-	return rid_b == rid_e ? rid_b : -1;
+	auto mirror = [&](int64_t p) { return p < R.l_pac ? p : 2 * R.l_pac - 1 - p; };
+	if (rb < R.l_pac && R.l_pac < re) return -2;
+	const int first = contig_of(R, mirror(rb));
+	if (re <= rb) return first;
+	return contig_of(R, mirror(re - 1)) == first ? first : -1;
 }
-// test_and_merge, comp_seed.cpp:182-203: 1 if the seed is contained in or appended to the chain
-inline bool test_and_merge(const cs_chain_params_t &opt, int64_t l_pac, Chain &c, const cs_seed_t &p, int seed_rid)
+// Does seed s belong to chain c (test_and_merge, comp_seed.cpp:182-203)?  Yes without a change when it lies inside the chain's
+// query and reference span; yes, appended, when it follows the chain's last seed on the same strand within the band `w` and
+// closer than max_chain_gap on both axes; otherwise a new chain starts.
+inline bool absorb(const cs_chain_params_t &opt, int64_t l_pac, Chain &c, const cs_seed_t &s, int seed_rid)
 {
-	const cs_seed_t &last = c.seeds.back(), &first = c.seeds.front();
-	const int64_t qend = last.qbeg + last.len, rend = last.rbeg + last.len;
 	if (seed_rid != c.rid) return false;
-	if (p.qbeg >= first.qbeg && p.qbeg + p.len <= qend && p.rbeg >= first.rbeg && p.rbeg + p.len <= rend) return true;
-	if ((last.rbeg < l_pac || first.rbeg < l_pac) && p.rbeg >= l_pac) return false;
-	const int64_t x = p.qbeg - last.qbeg, y = p.rbeg - last.rbeg;
-	if (y >= 0 && x - y <= opt.w && y - x <= opt.w && x - last.len < opt.max_chain_gap && y - last.len < opt.max_chain_gap) { c.seeds.push_back(p); return true; }
-	return false;
+	const cs_seed_t &head = c.seeds.front(), &tail = c.seeds.back();
+	const bool in_query = s.qbeg >= head.qbeg && s.qbeg + s.len <= tail.qbeg + tail.len;
+	const bool in_ref = s.rbeg >= head.rbeg && s.rbeg + s.len <= tail.rbeg + tail.len;
+	if (in_query && in_ref) return true;
+	const bool chain_fwd = tail.rbeg < l_pac || head.rbeg < l_pac;
+	if (chain_fwd && s.rbeg >= l_pac) return false;                       // never across the strands
+	const int64_t dq = (int64_t)s.qbeg - tail.qbeg, dr = s.rbeg - tail.rbeg;
+	const bool near_diag = dq - dr <= opt.w && dr - dq <= opt.w;
+	const bool close = dq - tail.len < opt.max_chain_gap && dr - tail.len < opt.max_chain_gap;
+	if (dr < 0 || !near_diag || !close) return false;
+	c.seeds.push_back(s);
+	return true;
 }
 
 struct ReadOut { std::vector<cs_chain_t> chains; std::vector<cs_seed_t> seeds; std::vector<uint32_t> per_read; };
@@ -154,10 +155,10 @@ void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs
 			tree.clear(); pool.clear();
 			for (uint64_t si = S.seed_off[r]; si < S.seed_off[r + 1]; ++si) {
 				const cs_seed_t &s = S.seeds[si];
-				const int rid = intv2rid(R, s.rbeg, s.rbeg + s.len);
+				const int rid = contig_of_seed(R, s.rbeg, s.rbeg + s.len);
 				if (rid < 0) continue; // bridging two sequences or the forward-reverse boundary (comp_seed.cpp:251)
 				bool add = true;
-				if (tree.size) { const int lo = tree.lower(s.rbeg); if (lo >= 0 && test_and_merge(opt, R.l_pac, pool[lo], s, rid)) add = false; }
+				if (tree.size) { const int lo = tree.lower(s.rbeg); if (lo >= 0 && absorb(opt, R.l_pac, pool[lo], s, rid)) add = false; }
 				if (add) { Chain c; c.pos = s.rbeg; c.rid = rid; c.seeds.push_back(s); pool.push_back(std::move(c)); tree.put(s.rbeg, (int32_t)pool.size() - 1); }
 			}
 			// fraction of the read covered by repetitive mems (comp_seed.cpp:271-280); the mems are sorted by interval
@@ -171,7 +172,7 @@ void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs
 			const float frac = (float)l_rep / len;
 			auto emit = [&](int32_t id) {
 				const Chain &c = pool[id];
-				cs_chain_t o; o.pos = c.pos; o.rid = c.rid; o.n_seeds = (int32_t)c.seeds.size(); o.frac_rep = frac; o.is_alt = 0;
+				cs_chain_t o; o.pos = c.pos; o.rid = c.rid; o.n_seeds = (int32_t)c.seeds.size(); o.frac_rep = frac; o.is_alt = R.is_alt[(size_t)c.rid]; // comp_seed.cpp:259
 				out.chains.push_back(o); out.seeds.insert(out.seeds.end(), c.seeds.begin(), c.seeds.end());
 				++n_out;
 			};
@@ -182,7 +183,9 @@ void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs
 }
 } // namespace
 
-// contig table from <prefix>.ann (bns_restore_core, bntseq.c:97-140: "l_pac n_seqs seed", then per sequence "gi name [comment]" and "offset len n_ambs")
+// contig table from <prefix>.ann (bns_restore_core, bntseq.c:97-140: "l_pac n_seqs seed", then per sequence "gi name [comment]" and
+// "offset len n_ambs"), ALT flags from <prefix>.alt where that file exists (bns_restore, bntseq.c:178-207: the first field of every
+// line that does not start with '@' names an ALT contig; a last line without a newline is not looked at)
 extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
 {
 	if (!prefix || !out) return cs_fail_(CS_EINVAL, "cs_chainer_create: null argument");
@@ -194,15 +197,30 @@ extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
 	bool ok = fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) == 3 && n_seqs > 0;
 	c->ref.l_pac = l_pac;
 	std::vector<char> line(1 << 16);
+	std::unordered_map<std::string, int> by_name; // (the reference's hash keeps the last contig of a repeated name)
 	if (ok) ok = fgets(line.data(), (int)line.size(), fp) != nullptr; // rest of the first line
 	for (int i = 0; ok && i < n_seqs; ++i) {
-		long long off = 0; int len = 0, n_ambs = 0;
-		ok = fgets(line.data(), (int)line.size(), fp) != nullptr;                       // "gi name [comment]"
+		long long off = 0; int len = 0, n_ambs = 0; unsigned gi = 0;
+		std::vector<char> name(8192);
+		ok = fscanf(fp, "%u%8191s", &gi, name.data()) == 2;                               // "gi name", then the comment up to the end of the line
+		ok = ok && fgets(line.data(), (int)line.size(), fp) != nullptr;
 		ok = ok && fscanf(fp, "%lld%d%d", &off, &len, &n_ambs) == 3;
-		if (ok) { c->ref.offset.push_back(off); c->ref.len.push_back(len); ok = fgets(line.data(), (int)line.size(), fp) != nullptr || i == n_seqs - 1; }
+		if (ok) { by_name[name.data()] = i; c->ref.offset.push_back(off); c->ref.len.push_back(len); ok = fgets(line.data(), (int)line.size(), fp) != nullptr || i == n_seqs - 1; }
 	}
 	fclose(fp);
 	if (!ok) { delete c; return cs_fail_(CS_EIO, std::string(prefix) + ".ann is malformed"); }
+	c->ref.is_alt.assign((size_t)n_seqs, 0);
+	if ((fp = fopen((std::string(prefix) + ".alt").c_str(), "r")) != nullptr) {
+		std::string field; bool in_field = true; int ch;
+		while ((ch = fgetc(fp)) != EOF) {
+			if (ch == '\n') {
+				if (in_field || !field.empty()) { if (!field.empty() && field[0] != '@') { auto it = by_name.find(field); if (it != by_name.end()) c->ref.is_alt[(size_t)it->second] = 1; } }
+				field.clear(); in_field = true;
+			} else if (in_field && (ch == '\t' || ch == '\r')) in_field = false;
+			else if (in_field) field.push_back((char)ch);
+		}
+		fclose(fp);
+	}
 	*out = c;
 	return CS_OK;
 }

@@ -34,6 +34,7 @@ static void usage()
 	        "       -K INT        process INT input bases in each batch [10000000 x -t]\n"
 	        "GPU / output options:\n"
 	        "       --gpus INT    number of MI355X to shard each batch over [all visible]\n"
+	        "       --devices LIST   comma-separated device ordinal of every shard instead (an ordinal may repeat)\n"
 	        "       --no-sal      stop after SMEM collection (no suffix-array lookup)\n"
 	        "       --dump-seeds FILE   write `M read beg end x0 x1 x2` and `S read qbeg len rbeg` lines\n"
 	        "Other CompSeed flags (-w -d -D -W -m -S -P -A -B -O -E -L -U -x -p -R -H -o -j -5 -q -v -T -h -a -C -V -Y -M -I)\n"
@@ -45,6 +46,7 @@ int main(int argc, char **argv)
 	setenv("GPU_MAX_HW_QUEUES", "8", 0); // before the HIP runtime starts: one engine per GPU, each with streams of its own
 	cs_params_t par; cs_params_default(&par);
 	int n_threads = 1, n_gpus = -1, verbose = 0; long fixed_chunk = 0; const char *dump = nullptr;
+	std::vector<int> devices; // --devices: the device ordinal of every shard (an ordinal may repeat: several engines on one GPU)
 	std::vector<const char *> pos;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -57,6 +59,7 @@ int main(int argc, char **argv)
 		else if (a == "-t") { n_threads = atoi(need()); if (n_threads < 1) n_threads = 1; }
 		else if (a == "-K") fixed_chunk = atol(need());
 		else if (a == "--gpus") n_gpus = atoi(need());
+		else if (a == "--devices") { for (const char *q = need(); *q;) { devices.push_back((int)strtol(q, (char **)&q, 10)); if (*q == ',') ++q; else if (*q) { usage(); return 1; } } }
 		else if (a == "--no-sal") par.want_sal = 0;
 		else if (a == "-v") verbose = atoi(need()) >= 4 ? 1 : 0; // bwa's verbosity levels: 4 = debugging output
 		else if (a == "--dump-seeds") dump = need();
@@ -73,13 +76,15 @@ int main(int argc, char **argv)
 	cs_index_view_t view; cs_index_view(idx, &view);
 	int ndev = 0;
 	if (cs_device_count(&ndev) || ndev < 1) { fprintf(stderr, "[E::main] no MI355X visible: %s\n", cs_last_error()); return 1; }
-	if (n_gpus < 1 || n_gpus > ndev) n_gpus = ndev;
+	if (!devices.empty()) n_gpus = (int)devices.size();
+	else { if (n_gpus < 1 || n_gpus > ndev) n_gpus = ndev; for (int g = 0; g < n_gpus; ++g) devices.push_back(g); }
+	for (int d : devices) if (d < 0 || d >= ndev) { fprintf(stderr, "[E::main] --devices: no device %d (%d visible)\n", d, ndev); return 1; }
 	std::vector<cs_engine_t *> eng((size_t)n_gpus, nullptr);
 	cs_engine_options_t eopt; cs_engine_options_default(&eopt);
 	eopt.count_sal_merged = 1; // "SA Lookup: ... calls, % merged" as CompSeed prints it (main.cpp:209-210)
 	eopt.verbose = verbose;
 	for (int g = 0; g < n_gpus; ++g)
-		if (cs_engine_create_opts(&view, g, &eopt, &eng[g])) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); return 1; }
+		if (cs_engine_create_opts(&view, devices[(size_t)g], &eopt, &eng[g])) { fprintf(stderr, "[E::main] GPU %d: %s\n", g, cs_last_error()); return 1; }
 
 	FILE *fo = dump ? fopen(dump, "w") : nullptr;
 	if (dump && !fo) { fprintf(stderr, "[E::main] cannot write %s\n", dump); return 1; }

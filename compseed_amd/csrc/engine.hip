@@ -7,6 +7,7 @@
 #include "smem_split.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -436,6 +437,7 @@ extern "C" int cs_engine_create_opts(const cs_index_view_t *index, int device, c
 }
 
 static void pipe_stop(cs_engine *e);
+static bool pipe_busy(const cs_engine *e);
 extern "C" void cs_engine_destroy(cs_engine_t *e)
 {
 	if (!e) return;
@@ -479,7 +481,7 @@ extern "C" int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st)
 }
 extern "C" void cs_engine_reset_stats(cs_engine_t *e)
 {
-	if (!e) return;
+	if (!e || pipe_busy(e)) return; // (the seeding thread owns the counters while batches are in flight)
 	memset(&e->st, 0, sizeof e->st);
 	e->stream_bytes = 0;
 	(void)hipSetDevice(e->device);
@@ -489,6 +491,7 @@ extern "C" void cs_engine_reset_stats(cs_engine_t *e)
 extern "C" int cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out)
 {
 	if (!e || !out) return fail(CS_EINVAL, "null argument");
+	if (pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_traffic_model: submitted batches are in flight, collect them first");
 	HIP_TRY(hipSetDevice(e->device));
 	HIP_TRY(hipMemcpyAsync(&out->events[0][0], e->d_evc.p, (size_t)N_KID * N_EV * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -755,9 +758,11 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 		// which reads still have calls in the queue (their mem lists are not final; for all others the text answers everything)
 		HIP_TRY(hipMemsetAsync(e->d_pending.p, 0, (size_t)nb, s));
 		if (queue) hipLaunchKernelGGL(mark_pending_kernel, dim3((unsigned)e->n_cu * 4), dim3(256), 0, s, queue, queue_n, fq_cap, nb, e->d_pending.p);
+		// the snapshot of the mem counts is taken on the main stream, between two iterations: every entry below a count is complete
+		// (on the side stream it could run beside the next iteration's kernels, which bump a count before they store the mem)
+		HIP_TRY(hipMemcpyAsync(e->d_cnt_snap.p, e->d_cnt.p, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 		HIP_TRY(hipEventRecord(e->ev_r3a, s));
 		HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_r3a, 0));
-		HIP_TRY(hipMemcpyAsync(e->d_cnt_snap.p, e->d_cnt.p, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream2));
 		hipLaunchKernelGGL(r3text_kernel, dim3((unsigned)std::min<uint64_t>((uint64_t)e->n_cu * 16, ((uint64_t)nb + 255) / 256)), dim3(256), 0, e->stream2, A,
 		                   (const uint32_t *)e->d_cnt_snap.p, C + 15, (const uint8_t *)e->d_pending.p);
 		HIP_TRY(hipGetLastError());
@@ -1202,7 +1207,7 @@ struct HostPipe {
 	bool started = false, quit = false;
 	std::deque<HostJob> q_up, q_seed; std::deque<XJob> q_x; bool x_busy = false;
 	int in_free[2] = {1, 1};
-	uint64_t n_submitted = 0, n_collected = 0, parts_seen = 0;
+	std::atomic<uint64_t> n_submitted{0}, n_collected{0}; uint64_t parts_seen = 0; // (one submitting and one collecting thread may run at the same time)
 	long long handed = -1;               // batch whose pinned result slot the caller currently holds (until its next collect)
 	BatchState bs[2];
 };
@@ -1357,7 +1362,7 @@ static void pipe_stop(cs_engine *e)
 	if (hp.th_x.joinable()) hp.th_x.join();
 	delete e->hp; e->hp = nullptr;
 }
-static bool pipe_busy(const cs_engine *e) { return e->hp && e->hp->n_submitted != e->hp->n_collected; }
+static bool pipe_busy(const cs_engine *e) { return e->hp && e->hp->n_submitted.load() != e->hp->n_collected.load(); }
 
 static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets, bool expand)
 {
@@ -1367,7 +1372,7 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	HIP_TRY(hipSetDevice(e->device));
 	if (!e->hp) e->hp = new HostPipe();
 	HostPipe &hp = *e->hp;
-	if (hp.n_submitted - hp.n_collected >= 2) return fail(CS_EINVAL, "cs_engine_submit: two batches are in flight already, collect one first");
+	if (hp.n_submitted.load() - hp.n_collected.load() >= 2) return fail(CS_EINVAL, "cs_engine_submit: two batches are in flight already, collect one first");
 	uint64_t n_bases = 0, max_len = 0;
 	if (n_reads > 0) {
 		if (offsets[0] != 0) return fail(CS_EINVAL, "offsets[0] must be 0");
@@ -1379,7 +1384,7 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 		}
 		if (max_len >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
 	}
-	const uint64_t id = hp.n_submitted;
+	const uint64_t id = hp.n_submitted.load();
 	const int rs = (int)(id & 1);
 	// parts: contiguous read ranges of about pipeline_reads reads (one, if the batch is not much larger than that)
 	std::vector<HostJob> parts;
@@ -1396,10 +1401,13 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	}
 	{ // buffers the threads will use: sized here, while no part of this batch is in flight (earlier batches never need more than they have)
 		std::unique_lock<std::mutex> lk(hp.mu);
-		const bool idle = hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1];
 		if (in_cap + 64 > e->hp_in[0].cap || off_cap > e->hp_inoff[0].cap || off_cap > e->hp_pk_moff[0].cap || (par->want_sal && off_cap > e->hp_pk_soff[0].cap)) {
-			if (!idle) hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[rs ^ 1].parts_queued == hp.bs[rs ^ 1].parts_total); });
+			// a reallocation frees buffers the other batch may still be using: not only while its parts are queued or being seeded
+			// (the input slots are given back right after seed_device_impl), but until the seeding thread has queued the pack kernels
+			// and downloads of its LAST part (parts_queued == parts_total) and those have drained (s_down below)
+			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[rs ^ 1].parts_queued == hp.bs[rs ^ 1].parts_total); });
 			lk.unlock();
+			HIP_TRY(hipStreamSynchronize(e->stream));
 			HIP_TRY(hipStreamSynchronize(e->s_down));
 			for (int k = 0; k < 2; ++k) {
 				CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
@@ -1425,10 +1433,10 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 {
 	if (!e || !out) return fail(CS_EINVAL, "cs_engine_collect: null argument");
-	if (!e->hp || e->hp->n_submitted == e->hp->n_collected) return fail(CS_EINVAL, "cs_engine_collect: nothing has been submitted");
+	if (!e->hp || e->hp->n_submitted.load() == e->hp->n_collected.load()) return fail(CS_EINVAL, "cs_engine_collect: nothing has been submitted");
 	HIP_TRY(hipSetDevice(e->device));
 	HostPipe &hp = *e->hp;
-	const uint64_t id = hp.n_collected;
+	const uint64_t id = hp.n_collected.load();
 	const int rs = (int)(id & 1);
 	BatchState &b = hp.bs[rs];
 	{
@@ -1455,8 +1463,10 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 	out->mem_format = b.pk16 ? CS_MEM_PACKED16 : CS_MEM_FULL32;
 	out->mem_off = e->hp_moff[rs].p; out->mems = e->hp_mems[rs].p;
 	out->seed_off = b.sal ? e->hp_soff[rs].p : nullptr; out->seed_rbeg = b.sal ? e->hp_rbeg[rs].p : nullptr;
-	// cs_engine_result_digest / gather_reads work on the device-side result, which is the whole batch only if it was not cut
-	e->last.valid = b.parts_total == 1 && !pipe_busy(e); e->last.n_reads = b.n_reads; e->last.n_mems = b.mem_base; e->last.n_seeds = b.seed_base; e->last.want_sal = b.sal;
+	{ // cs_engine_result_digest / gather_reads work on the device-side result, which is the whole batch only if it was not cut
+		std::lock_guard<std::mutex> lk(hp.mu); // (a submit on another thread invalidates it under the same lock)
+		e->last.valid = b.parts_total == 1 && !pipe_busy(e); e->last.n_reads = b.n_reads; e->last.n_mems = b.mem_base; e->last.n_seeds = b.seed_base; e->last.want_sal = b.sal;
+	}
 	return CS_OK;
 }
 

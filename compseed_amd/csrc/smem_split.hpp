@@ -209,7 +209,15 @@ __global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64
 				const uint32_t sh = (uint32_t)(a - a0) << 3;
 				uint64_t v[5];
 #pragma unroll
-				for (int q = 0; q < 5; ++q) v[q] = (!RAW || a0 + 8u * (uint32_t)q < n_bases) ? w[q] : 0x0404040404040404ull;
+				for (int q = 0; q < 5; ++q) {
+					const uint64_t wa = a0 + 8u * (uint32_t)q;
+					if (!RAW || wa + 8 <= n_bases) v[q] = w[q];
+					else { // the word that holds the caller's last bytes: assembled bytewise, nothing behind n_bases is read
+						uint64_t t = 0x0404040404040404ull;
+						for (uint64_t z = wa; z < n_bases; ++z) t = (t & ~(0xffull << ((z - wa) << 3))) | (uint64_t)seq[z] << ((z - wa) << 3);
+						v[q] = t;
+					}
+				}
 				uint64_t bases = 0; uint32_t bad = 0;
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {

@@ -43,13 +43,13 @@ def merge_csr(parts):
 class Dist:
     """Thin wrapper over torch.distributed for the launch contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from env)."""
 
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, local=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0")) if local is None else int(local)   # device ordinal of this rank
         self.backend = backend
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -186,9 +186,8 @@ void cs_engine_destroy(cs_engine_t *e);
  *      memory.  Device variant: pointers are device memory on the engine's GPU and the result arrays are device
  *      pointers (no PCIe traffic inside the call).  The engine works on streams of its own: device inputs must be
  *      COMPLETE when the call is made (synchronise the stream that produced them first), d_offsets[0] must be 0 and
- *      d_offsets[n_reads] == n_bases (checked: CS_EINVAL); results are complete when the call returns.  The base
- *      buffer is read in aligned 8-byte words: it must be readable up to the next multiple of 8 behind n_bases (any
- *      device allocation is). */
+ *      d_offsets[n_reads] == n_bases (checked: CS_EINVAL); results are complete when the call returns.  Nothing behind
+ *      d_bases[n_bases - 1] is read. */
 int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                           const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
 int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
@@ -225,7 +224,9 @@ int  cs_engine_seed_batch_packed(cs_engine_t *e, const cs_params_t *par, int64_t
  * buffers must stay untouched until the batch is collected), cs_engine_collect_packed blocks until the OLDEST submitted batch is complete.
  * With two batches kept submitted the upload of batch n+1, the seeding of batch n and the download of batch n-1 overlap, and throughput is
  * that of the slowest of the three instead of their sum.  A collected result stays valid until the next collect or blocking seed call.
- * While batches are in flight the engine's other entry points that use the device return CS_EINVAL. */
+ * While batches are in flight the engine's other entry points that use the device return CS_EINVAL (cs_engine_reset_stats does nothing).
+ * Threads: cs_engine_submit may be called from ONE thread while cs_engine_collect_packed runs on ONE other thread (the reader and the
+ * processing step of a kt_pipeline, main.cpp:60-126); everything else on an engine needs the caller's own serialisation. */
 int  cs_engine_submit(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets);
 int  cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out);
 static inline void cs_unpack_mem(const cs_packed_result_t *r, uint64_t i, cs_intv_t *m)

@@ -99,6 +99,19 @@ int cso_seed_batch(const cso_index_t *idx, const cso_params_t *par, int64_t n_re
                    uint64_t **mem_off, cso_intv_t **mems, uint64_t **seed_off, cso_seed_t **seeds, cso_stats_t *st);
 void cso_free(void *p);
 
+/* ---- banded Smith-Waterman seed extension (cs_bsw_oracle.c): ksw_extend2 (bwalib/ksw.c:380) restated.  Sequences are codes 0..4. */
+typedef struct { int8_t mat[25]; int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus; } cso_bsw_params_t;
+typedef struct { uint64_t q_off, t_off; int32_t qlen, tlen, h0, pad; } cso_bsw_pair_t;
+typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } cso_bsw_result_t;
+void cso_bsw_params_default(cso_bsw_params_t *P);
+int  cso_bsw_score(const cso_bsw_params_t *P, int vec_rule, int t, int q);
+int  cso_bsw_uses_vec_rule(const cso_bsw_params_t *P, int qlen, int tlen, int h0);
+/* vec_rule 0: ksw_extend2 / scalarBandedSWA (the matrix); 1: getScores8 / getScores16 (compare the codes); cso_extend_pair picks as the reference does */
+int  cso_extend_pair_rule(const cso_bsw_params_t *P, int vec_rule, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int w, int h0, cso_bsw_result_t *out);
+int  cso_extend_pair(const cso_bsw_params_t *P, int qlen, const uint8_t *query, int tlen, const uint8_t *target, int w, int h0, cso_bsw_result_t *out);
+int  cso_extend_batch(const cso_bsw_params_t *P, int64_t n, const cso_bsw_pair_t *pairs, const uint8_t *qbuf, const uint8_t *tbuf, int w,
+                      int n_threads, cso_bsw_result_t *out);
+
 extern const uint8_t cso_nt4_table[256]; /* ASCII -> 0..4 ('-' -> 5), same mapping as nst_nt4_table (bntseq.c:46) */
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@ What is produced (all data, no reference source text):
   g1/<reads>.<params>.chains.npz     the chains the reference's mem_chain (comp_seed.cpp:241) builds from those mems and seeds
   g1/prims.npz                       known-answer vectors for bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_sa
   MANIFEST.json                      md5 of every file + the harness stderr summary per run
+  alt1/                              `make_golden.py alt`: main100's chains with a <prefix>.alt file naming chr2 (is_alt of the chains)
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
                                      md5 digests of its complete output (`make_golden.py config1` regenerates only this)
 """
@@ -184,11 +185,35 @@ def make_config1():
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "digest"} for k, v in out["sets"].items()}, indent=1))
 
 
+def make_alt():
+    """alt1/: the reference's chains for main100 when the index has a <prefix>.alt file that names chr2 (bns_restore, bntseq.c:178-207):
+    is_alt of every chain on that contig is 1 (comp_seed.cpp:261).  The index files are g1's, linked into a scratch prefix."""
+    import shutil, tempfile
+    d = os.path.join(HERE, "alt1"); os.makedirs(d, exist_ok=True)
+    alt = os.path.join(d, "ref.alt")
+    open(alt, "w").write("@SQ\tSN:chr2\tLN:1\nchr2\t0\tchr1\t100\t60\t50M\t*\t0\t0\t*\t*\nnot_a_contig\nchr1")   # header line, an ALT line, an unknown name,
+    with tempfile.TemporaryDirectory() as td:                                                                    # and a last line without a newline (ignored)
+        for ext in ("bwt", "sa", "pac", "ann", "amb"):
+            os.symlink(os.path.join(HERE, "g1", "ref." + ext), os.path.join(td, "ref." + ext))
+        shutil.copy(alt, os.path.join(td, "ref.alt"))
+        tmp, ctmp = os.path.join(td, "o.bin"), os.path.join(td, "c.bin")
+        r = run([os.path.join(REFBIN, "ref_dump"), os.path.join(td, "ref"), os.path.join(HERE, "g1", "main100.txt"), tmp, "--chains", ctmp])
+        if r.returncode:
+            sys.exit(r.stderr)
+        ch = parse_chains(ctmp)
+    assert set(ch["is_alt"][ch["rid"] == 1].tolist()) == {1} and set(ch["is_alt"][ch["rid"] == 0].tolist()) == {0}
+    np.savez_compressed(os.path.join(d, "main100.default.chains.npz"), **ch)
+    json.dump({fn: md5(os.path.join(d, fn)) for fn in sorted(os.listdir(d)) if fn != "MANIFEST.json"}, open(os.path.join(d, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print("alt1: %d chains, %d on the ALT contig" % (ch["pos"].size, int(ch["is_alt"].sum())))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
     if len(sys.argv) > 1 and sys.argv[1] == "config1":
         return make_config1()
+    if len(sys.argv) > 1 and sys.argv[1] == "alt":
+        return make_alt()
     rng = random.Random(20261003)
     d = os.path.join(HERE, "g1")
     os.makedirs(d, exist_ok=True)

@@ -52,3 +52,26 @@ def test_goldens_exercise_the_tree():
     assert len(dup) >= 3
     for r in range(per_read.size):
         assert (np.diff(zc["pos"][co[r]:co[r + 1]]) >= 0).all()     # traversal order is key order
+
+
+def test_alt_contigs_are_flagged_like_the_reference(tmp_path):
+    """an index with a <prefix>.alt file (hs38DH-style): the chainer reads it as bns_restore does (FM_index/bntseq.c:178-207) and the chains
+    on the named contig carry is_alt = 1 (comp_seed.cpp:261); golden: the reference's own mem_chain run on such a prefix
+    (tests/golden/make_golden.py alt).  The .alt fixture also has a header line, an unknown name and a last line without a newline."""
+    import shutil
+    import compseed_amd as ca
+    alt_dir = os.path.join(os.path.dirname(_data.GOLD), "alt1")
+    shutil.copy(_data.PREFIX + ".ann", tmp_path / "ref.ann")
+    shutil.copy(os.path.join(alt_dir, "ref.alt"), tmp_path / "ref.alt")
+    z, kw = _data.load_golden("main100", "default")
+    zc = np.load(os.path.join(alt_dir, "main100.default.chains.npz"))
+    _, off = _data.load_reads("main100")
+    mems = np.zeros(z["mems"].shape[0], dtype=ca.INTV_DT)
+    mems["x0"], mems["x1"], mems["x2"], mems["info"] = z["mems"][:, 0], z["mems"][:, 1], z["mems"][:, 2], z["mems"][:, 3]
+    seeds = np.zeros(z["seed_rbeg"].size, dtype=ca.SEED_DT)
+    seeds["rbeg"], seeds["qbeg"], seeds["len"] = z["seed_rbeg"], z["seed_qbeg"], z["seed_len"]
+    c = ca.Chainer(str(tmp_path / "ref"))
+    got = c.chain(z["mem_off"], mems, z["seed_off"], seeds, off, ca.ChainParams(), threads=2)
+    check_chains(got, zc)
+    assert set(zc["is_alt"].tolist()) == {0, 1}
+    c.close()

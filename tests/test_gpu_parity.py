@@ -563,3 +563,56 @@ def test_engine_output_chains_like_the_reference(eng, name, pname):
     c = ca.Chainer(_data.PREFIX)
     check_chains(c.chain(r.mem_off, r.mems, r.seed_off, r.seeds, off, ca.ChainParams(k=kw.get("k", 19), c=kw.get("c", 500)), threads=4), golden_chains(name, pname))
     c.close()
+
+
+def test_cli_shards_over_two_engines_on_one_gpu(tmp_path):
+    """the sharded path of the C++ drop-in on a one-GPU box: --devices 0,0 puts both shards' engines on the same GPU (every chunk split into
+    two contiguous read ranges, two engines, two submit / collect pipelines at once); same dump as one engine, also with -K chunks"""
+    import subprocess
+    import compseed_amd as ca
+    cli = os.path.join(os.path.dirname(ca.lib_path()), "compseed_amd_cli")
+    outs = []
+    for dev in (("--gpus", "1"), ("--devices", "0,0"), ("--devices", "0,0,0")):
+        out = tmp_path / ("seeds%d.txt" % len(outs))
+        r = subprocess.run([cli, "-K", "30000", *dev, "--dump-seeds", str(out), _data.PREFIX, os.path.join(_data.GOLD, "main100.txt")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("on %d GPU(s)" % (1 if dev[0] == "--gpus" else dev[1].count(",") + 1)) in r.stderr
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") > 10000
+
+
+def test_submit_growing_batches_while_the_other_is_in_flight():
+    """a batch that needs LARGER input / offset buffers is submitted while the previous one is still somewhere in the
+    seeding thread (seeded, its pack kernels and downloads not yet queued).  The reallocation has to wait for it: every result must still be
+    the golden's.  Batches grow from 40 reads to 3000 and shrink again, two in flight throughout, several rounds, on a fresh engine each
+    round (a DevBuf has no slack on its first allocation, which is when the race was open)."""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    z, _ = _data.load_golden("main100", "default")
+    bases, off = _data.load_reads("main100")
+    n = off.size - 1
+    want_m = z["mems"]; mo = z["mem_off"].astype(np.int64); so = z["seed_off"].astype(np.int64)
+
+    def sub(k0, k1):
+        pin = ca.pinned_array(int(off[k1] - off[k0])); pin[:] = bases[int(off[k0]):int(off[k1])]
+        return pin, (off[k0:k1 + 1] - off[k0]).astype(np.uint64), (k0, k1)
+    sizes = [40, 90, 400, 1300, 3000, 700, 2900, 60, 3000]
+    for rnd in range(3):
+        e = ca.Engine(ix, 0, pipeline_reads=350 if rnd else 5000000)
+        jobs = []
+        for j, sz in enumerate(sizes):
+            k0 = (j * 131 + rnd * 17) % (n - sz + 1)
+            jobs.append(sub(k0, k0 + sz))
+        e.submit(jobs[0][0], jobs[0][1]); e.submit(jobs[1][0], jobs[1][1])
+        for i in range(len(jobs)):
+            p = e.collect_packed()
+            k0, k1 = jobs[i][2]
+            mems, seeds = _expand_packed(p)
+            assert np.array_equal(p["mem_off"].astype(np.int64), mo[k0:k1 + 1] - mo[k0]), (rnd, i)
+            assert np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), want_m[mo[k0]:mo[k1]]), (rnd, i)
+            assert np.array_equal(seeds["rbeg"], z["seed_rbeg"][so[k0]:so[k1]]), (rnd, i)
+            if i + 2 < len(jobs):
+                e.submit(jobs[i + 2][0], jobs[i + 2][1])
+        e.close()
+    ix.close()
