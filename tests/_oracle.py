@@ -49,7 +49,7 @@ def lib():
     if _lib is None:
         src_newer = (not os.path.exists(LIB_PATH) or
                      any(os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
-                         for f in ("cs_oracle.c", "cs_oracle.h", "cs_index_naive.c")))
+                         for f in ("cs_oracle.c", "cs_oracle.h", "cs_index_naive.c", "cs_bsw_oracle.c")))
         if src_newer:
             subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, capture_output=True)
         L = C.CDLL(LIB_PATH)
@@ -158,3 +158,72 @@ class OracleIndex:
         for p in (mo, mm, so, ss):
             lib().cso_free(p)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# banded Smith-Waterman seed extension (oracle/cs_bsw_oracle.c) and its fixtures (tests/golden/bsw1/, from the real reference)
+BSW_PAIR_DT = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("h0", "<i4"), ("pad", "<i4")])
+BSW_RES_DT = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"), ("max_off", "<i4")])
+BSW_DIR = os.path.join(ROOT, "tests", "golden", "bsw1")
+
+
+class BswParams(C.Structure):
+    _fields_ = [("mat", C.c_int8 * 25), ("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32), ("e_ins", C.c_int32),
+                ("zdrop", C.c_int32), ("end_bonus", C.c_int32)]
+
+
+def bsw_fixture(tag):
+    """tests/golden/bsw1/<tag>.bsw.npz -> dict(mat, meta [n,17] = kind w zdrop end_bonus o_del e_del o_ins e_ins qlen tlen h0 | score qle tle gtle
+    gscore max_off, pairs (BSW_PAIR_DT), qbuf, tbuf, want (BSW_RES_DT))"""
+    z = np.load(os.path.join(BSW_DIR, tag + ".bsw.npz"))
+    meta = z["meta"]
+    pairs = np.zeros(meta.shape[0], dtype=BSW_PAIR_DT)
+    pairs["q_off"], pairs["t_off"] = z["q_off"][:-1], z["t_off"][:-1]
+    pairs["qlen"], pairs["tlen"], pairs["h0"] = meta[:, 8], meta[:, 9], meta[:, 10]
+    want = np.zeros(meta.shape[0], dtype=BSW_RES_DT)
+    for i, n in enumerate(BSW_RES_DT.names):
+        want[n] = meta[:, 11 + i]
+    return dict(mat=z["mat"], meta=meta, pairs=pairs, qbuf=z["qbuf"].copy(), tbuf=z["tbuf"].copy(), want=want)
+
+
+def bsw_groups(meta):
+    """indices of the records grouped by (w, zdrop, end_bonus, o_del, e_del, o_ins, e_ins): one extender object / one call each"""
+    keys = {}
+    for i, row in enumerate(meta[:, 1:8]):
+        keys.setdefault(tuple(int(x) for x in row), []).append(i)
+    return {k: np.array(v, dtype=np.int64) for k, v in keys.items()}
+
+
+def bsw_params(mat, key):
+    P = BswParams()
+    for i in range(25):
+        P.mat[i] = int(mat[i])
+    _, P.zdrop, P.end_bonus, P.o_del, P.e_del, P.o_ins, P.e_ins = key
+    return P
+
+
+def bsw_extend(fx, rule=None, threads=4):
+    """the oracle on every record of a fixture; rule None = the reference's dispatch per pair, 0 = matrix (ksw_extend2), 1 = vector rule"""
+    L = lib()
+    L.cso_extend_batch.argtypes = [C.POINTER(BswParams), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.cso_extend_pair_rule.argtypes = [C.POINTER(BswParams), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    got = np.zeros(fx["meta"].shape[0], dtype=BSW_RES_DT)
+    qb, tb = np.ascontiguousarray(fx["qbuf"]), np.ascontiguousarray(fx["tbuf"])
+    if qb.size == 0:
+        qb = np.zeros(1, np.uint8)
+    if tb.size == 0:
+        tb = np.zeros(1, np.uint8)
+    for key, idx in bsw_groups(fx["meta"]).items():
+        P = bsw_params(fx["mat"], key)
+        if rule is None:
+            pr = np.ascontiguousarray(fx["pairs"][idx]); out = np.zeros(idx.size, dtype=BSW_RES_DT)
+            assert L.cso_extend_batch(C.byref(P), idx.size, pr.ctypes.data, qb.ctypes.data, tb.ctypes.data, key[0], threads, out.ctypes.data) == 0
+            got[idx] = out
+        else:
+            one = np.zeros(1, dtype=BSW_RES_DT)
+            for i in idx:
+                p = fx["pairs"][i]
+                assert L.cso_extend_pair_rule(C.byref(P), rule, int(p["qlen"]), qb.ctypes.data + int(p["q_off"]), int(p["tlen"]), tb.ctypes.data + int(p["t_off"]),
+                                              key[0], int(p["h0"]), one.ctypes.data) == 0
+                got[i] = one[0]
+    return got

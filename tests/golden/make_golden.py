@@ -13,6 +13,8 @@ What is produced (all data, no reference source text):
   g1/<reads>.<params>.chains.npz     the chains the reference's mem_chain (comp_seed.cpp:241) builds from those mems and seeds
   g1/prims.npz                       known-answer vectors for bwt_occ4 / bwt_2occ4 / bwt_extend / bwt_sa
   MANIFEST.json                      md5 of every file + the harness stderr summary per run
+  bsw1/                              `make_golden.py bsw`: every banded-SW extension the reference performed on the read sets (inputs + 6 outputs),
+                                     recorded from its own run, and known answers of its scalar ksw_extend2
   alt1/                              `make_golden.py alt`: main100's chains with a <prefix>.alt file naming chr2 (is_alt of the chains)
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
                                      md5 digests of its complete output (`make_golden.py config1` regenerates only this)
@@ -207,6 +209,90 @@ def make_alt():
     print("alt1: %d chains, %d on the ALT contig" % (ch["pos"].size, int(ch["is_alt"].sum())))
 
 
+def parse_bsw(path):
+    """records of oracle/ref_bsw_trace.cpp / ref_ksw_kat.cpp -> (mat int8[25], meta int32[n,17], q_off, t_off, qbuf, tbuf)"""
+    raw = open(path, "rb").read()
+    assert raw[:7] == b"CSBSW01"
+    mat = np.frombuffer(raw, dtype=np.int8, count=25, offset=8).copy()
+    off, meta, qs, ts = 33, [], [], []
+    while off < len(raw):
+        r = np.frombuffer(raw, dtype="<i4", count=17, offset=off); off += 68
+        qs.append(raw[off:off + int(r[8])]); off += int(r[8])
+        ts.append(raw[off:off + int(r[9])]); off += int(r[9])
+        meta.append(r)
+    return mat, meta, qs, ts
+
+
+def save_bsw(path, mat, meta, qs, ts, cap):
+    """drop exact duplicates (tandem arrays extend the same pair hundreds of times), keep at most `cap` records at a constant stride"""
+    seen, keep = set(), []
+    for i, (r, q, t) in enumerate(zip(meta, qs, ts)):
+        key = (r.tobytes(), q, t)
+        if key not in seen:
+            seen.add(key); keep.append(i)
+    if len(keep) > cap:
+        keep = keep[::(len(keep) + cap - 1) // cap]
+    m = np.stack([meta[i] for i in keep]).astype(np.int32)
+    ql = np.array([len(qs[i]) for i in keep], dtype=np.uint64); tl = np.array([len(ts[i]) for i in keep], dtype=np.uint64)
+    q_off = np.zeros(len(keep) + 1, np.uint64); np.cumsum(ql, out=q_off[1:])
+    t_off = np.zeros(len(keep) + 1, np.uint64); np.cumsum(tl, out=t_off[1:])
+    np.savez_compressed(path, mat=mat, meta=m, q_off=q_off, t_off=t_off, qbuf=np.frombuffer(b"".join(qs[i] for i in keep), dtype=np.uint8),
+                        tbuf=np.frombuffer(b"".join(ts[i] for i in keep), dtype=np.uint8))
+    return len(meta), len(keep)
+
+
+def make_bsw():
+    """bsw1/: the banded Smith-Waterman extensions of the REAL reference.  oracle/_ref/CompSeed.bswtrace is the reference's own program
+    (main.cpp and all, -t 1) with the calls of mem_chain2aln_across_reads_V2 (comp_seed.cpp:1319) into BandedPairWiseSW::getScores8 /
+    getScores16 / scalarBandedSWAWrapper recorded by the linker-wrapped functions of oracle/ref_bsw_trace.cpp: query, target, h0, band,
+    the object's gap / Z-drop / end-bonus parameters and the six outputs the reference's code produced.  The read sets are g1's plus one
+    with insertions and deletions (g1's reads only carry substitutions); one run uses other scoring parameters.  kat_*.npz are known
+    answers of the reference's scalar ksw_extend2 (oracle/ref_ksw_kat.cpp) on generated pairs."""
+    import tempfile
+    d = os.path.join(HERE, "bsw1"); os.makedirs(d, exist_ok=True)
+    g1 = os.path.join(HERE, "g1")
+    rng = random.Random(20261004)
+    g = "".join(ln.strip() for ln in gzip.open(os.path.join(g1, "ref.fa.gz"), "rt") if not ln.startswith(">")).replace("N", "A")
+    reads = []
+    for _ in range(1200):  # 150-bp reads with 1..3 indels of 1..8 bases and 1 % substitutions, both strands
+        p = rng.randrange(0, len(g) - 200)
+        r = list(mutate(rng, g[p:p + 170], 0.01))
+        for _k in range(rng.randint(1, 3)):
+            at, gl = rng.randrange(15, 135), rng.choice([1, 1, 1, 2, 2, 3, 5, 8])
+            if rng.random() < 0.5:
+                del r[at:at + gl]
+            else:
+                r[at:at] = [rng.choice("ACGT") for _g in range(gl)]
+        r = "".join(r)[:150]
+        reads.append(revcomp(r) if rng.random() < 0.5 else r)
+    open(os.path.join(d, "indel150.txt"), "w").write("".join(x + "\n" for x in reads))
+    runs = [("main100", g1, [], 5000), ("sorted150", g1, [], 4000), ("ragged", g1, [], 5000), ("repeat100", g1, [], 3000), ("indel150", d, [], 5000),
+            ("indel150", d, ["-A", "2", "-B", "5", "-O", "7,7", "-E", "1,1", "-w", "30", "-d", "40", "-L", "3,7"], 3000),   # other scoring, symmetric unit-extension gaps
+            ("indel150", d, ["-A", "2", "-B", "5", "-O", "5,8", "-E", "2,1", "-w", "30", "-d", "40", "-L", "3,7"], 3000)]   # asymmetric gaps: see tests/test_oracle_bsw.py
+    summary = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, rd_dir, flags, cap in runs:
+            tr = os.path.join(td, "t.bin")
+            r = subprocess.run([os.path.join(REFBIN, "CompSeed.bswtrace"), "-t", "1", *flags, os.path.join(g1, "ref"), os.path.join(rd_dir, name + ".txt")],
+                               env=dict(os.environ, CS_BSW_TRACE=tr), capture_output=True, cwd=td)
+            if r.returncode:
+                sys.exit(r.stderr.decode()[-2000:])
+            tag = name + (".default" if not flags else ".scoring2" if "7,7" in flags else ".asym")
+            n_all, n_kept = save_bsw(os.path.join(d, tag + ".bsw.npz"), *parse_bsw(tr), cap)
+            summary[tag] = {"pairs_extended": n_all, "pairs_kept": n_kept, "flags": flags, "sam_md5": hashlib.md5(r.stdout).hexdigest()}
+        for a, b, n in ((1, 4, 6000), (2, 5, 2500)):
+            tr = os.path.join(td, "k.bin")
+            r = run([os.path.join(REFBIN, "ref_ksw_kat"), tr, str(n), "11", str(a), str(b)])
+            if r.returncode:
+                sys.exit(r.stderr)
+            tag = "kat_a%db%d" % (a, b)
+            n_all, n_kept = save_bsw(os.path.join(d, tag + ".bsw.npz"), *parse_bsw(tr), n)
+            summary[tag] = {"pairs_extended": n_all, "pairs_kept": n_kept}
+    summary["md5"] = {fn: md5(os.path.join(d, fn)) for fn in sorted(os.listdir(d)) if fn != "MANIFEST.json"}
+    json.dump(summary, open(os.path.join(d, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
@@ -214,6 +300,8 @@ def main():
         return make_config1()
     if len(sys.argv) > 1 and sys.argv[1] == "alt":
         return make_alt()
+    if len(sys.argv) > 1 and sys.argv[1] == "bsw":
+        return make_bsw()
     rng = random.Random(20261003)
     d = os.path.join(HERE, "g1")
     os.makedirs(d, exist_ok=True)
