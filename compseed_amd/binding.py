@@ -108,6 +108,28 @@ def unpack_mems16(p):
     return out
 
 
+EXT_PAIR_DT = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<i4"), ("tlen", "<i4"), ("h0", "<i4"), ("reserved", "<i4")])   # cs_ext_pair_t
+EXT_RES_DT = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"), ("gscore", "<i4"), ("max_off", "<i4")])       # cs_ext_result_t
+
+
+class ExtParams(C.Structure):
+    """cs_ext_params_t: the arguments of the reference's BandedPairWiseSW constructor (mapping/bandedSWA.h:117-121)"""
+    _fields_ = [("mat", C.c_int8 * 25), ("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32), ("e_ins", C.c_int32),
+                ("zdrop", C.c_int32), ("end_bonus", C.c_int32)]
+
+    def __init__(self, mat=None, o_del=6, e_del=1, o_ins=6, e_ins=1, zdrop=100, end_bonus=5, a=1, b=4):
+        super().__init__()
+        if mat is None:  # bwa_fill_scmat (bwalib/bwa.c:17-29)
+            mat = [(-1 if (i == 4 or j == 4) else a if i == j else -b) for i in range(5) for j in range(5)]
+        for i in range(25):
+            self.mat[i] = int(mat[i])
+        self.o_del, self.e_del, self.o_ins, self.e_ins, self.zdrop, self.end_bonus = o_del, e_del, o_ins, e_ins, zdrop, end_bonus
+
+
+class ExtStats(C.Structure):
+    _fields_ = [("pairs", C.c_uint64), ("cells", C.c_uint64), ("rows", C.c_uint64), ("launches", C.c_uint64), ("kernel_ms", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("bases", C.c_uint64), ("mems", C.c_uint64), ("seeds", C.c_uint64),
                 ("bwt_queries", C.c_uint64), ("bwt_calls", C.c_uint64), ("sal_queries", C.c_uint64),
@@ -232,6 +254,14 @@ def load_library():
     L.cs_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.cs_device_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.cs_device_sync.argtypes = [vp]
+    L.cs_ext_params_default.argtypes = [C.POINTER(ExtParams)]
+    L.cs_ext_params_default.restype = None
+    L.cs_extender_create.argtypes = [C.c_int, C.POINTER(ExtParams), C.POINTER(vp)]
+    L.cs_extender_destroy.argtypes = [vp]
+    L.cs_extender_destroy.restype = None
+    L.cs_extend_batch.argtypes = [vp, i64, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int32, vp]
+    L.cs_extend_batch_device.argtypes = [vp, i64, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int32, vp]
+    L.cs_extender_stats.argtypes = [vp, C.POINTER(ExtStats)]
     _lib = L
     return L
 
@@ -616,3 +646,42 @@ class Engine:
 
     def sync(self):
         _check(self._L.cs_device_sync(self._h))
+
+
+class Extender:
+    """cs_extender_t: the banded Smith-Waterman seed extension on the GPU (include/compseed_amd.h; the reference's BandedPairWiseSW)"""
+
+    def __init__(self, device=0, params=None):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _check(self.L.cs_extender_create(device, C.byref(params) if params is not None else None, C.byref(self.h)))
+
+    def extend(self, pairs, qbuf, tbuf, w=100):
+        """pairs: EXT_PAIR_DT array; qbuf / tbuf: uint8 codes 0..4.  Returns an EXT_RES_DT array (raises CSError on bad pairs)."""
+        pairs = np.ascontiguousarray(pairs, dtype=EXT_PAIR_DT)
+        qbuf = np.ascontiguousarray(qbuf, dtype=np.uint8); tbuf = np.ascontiguousarray(tbuf, dtype=np.uint8)
+        out = np.zeros(pairs.size, dtype=EXT_RES_DT)
+        self.last_rc = self.L.cs_extend_batch(self.h, pairs.size, pairs.ctypes.data if pairs.size else None, qbuf.ctypes.data if qbuf.size else None, qbuf.size,
+                                              tbuf.ctypes.data if tbuf.size else None, tbuf.size, int(w), out.ctypes.data if pairs.size else None)
+        self.last_out = out
+        _check(self.last_rc)
+        return out
+
+    def extend_device(self, d_pairs, n, d_q, q_bytes, d_t, t_bytes, d_out, w=100):
+        _check(self.L.cs_extend_batch_device(self.h, int(n), int(d_pairs), int(d_q), int(q_bytes), int(d_t), int(t_bytes), int(w), int(d_out)))
+
+    def stats(self):
+        st = ExtStats()
+        _check(self.L.cs_extender_stats(self.h, C.byref(st)))
+        return {n: getattr(st, n) for n, _ in ExtStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.L.cs_extender_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

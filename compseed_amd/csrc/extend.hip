@@ -1,0 +1,350 @@
+// extend.hip -- banded Smith-Waterman seed extension on gfx950 behind cs_extend_batch (include/compseed_amd.h).
+//
+// What it replaces: the extensions mem_chain2aln_across_reads_V2 (mapping/comp_seed.cpp:1319) hands, batch by batch, to
+// BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (mapping/bandedSWA.cpp:412, 1117, 242; call sites
+// comp_seed.cpp:1719, 1790, 1859, 1942, 2003, 2074): for a query (the read's bases beyond one end of a seed), a target (the reference
+// window beyond it) and the score h0 the seed has reached, the best score of an alignment that starts at the seed and extends into
+// both, and where it ends.  The definition is ksw_extend2 (bwalib/ksw.c:380-479): an affine-gap DP over a band of +-w diagonals that
+// also shrinks to the columns still alive, stops at a Z-drop, and reports six numbers.  Results are bit-identical to that definition
+// (tests/test_gpu_extend.py: every extension the reference performed on the golden read sets + its scalar code's known answers).
+//
+// Mapping: ONE WAVEFRONT PER PAIR, one query column per lane, rows in sequence.  A row of the reference's inner loop looks serial --
+// F(i, j+1) depends on F(i, j) -- but insertions open from the diagonal score M only (ksw.c:436,446: "100M3I3D20M" is disallowed), and
+// M(i, j) = H(i-1, j-1) + S depends on the previous row alone.  So with g(j) = max(M(j) - o_ins - e_ins, 0)
+//     F(j) = max over beg <= k < j of g(k) - (j - 1 - k) e_ins      =  [prefix maximum of g(k) + k e_ins]  -  (j - 1) e_ins,
+// one exclusive max-scan across the wave (6 DPP steps), and everything else in the row is element-wise: H = max(M, E, F), the new E, the
+// shift of H by one column for the next row's diagonal (one DPP move), the row maximum and its LAST column (a reduction + a ballot),
+// and the first / last live column for the adaptive band (two ballots).  The band state lives where the reference keeps it -- two
+// arrays over the query columns, here in LDS -- including what dropped columns last held, because a band that grows again reads it.
+// Queries longer than 64 columns take several chunks per row with the scan's carry handed on; queries too long for LDS use the same
+// code over a scratch area in HBM.  The target row base is a lane-indexed register window, re-read every 64 rows.
+//
+// This kernel is integer-compute-bound (VALU + cross-lane), not HBM-bound: a pair reads its two sequences once and writes 24 bytes.
+#include "cs_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include <hip/hip_runtime.h>
+
+#define HIP_TRYX(expr)                                                                              \
+	do {                                                                                            \
+		hipError_t e__ = (expr);                                                                    \
+		if (e__ != hipSuccess) {                                                                    \
+			(void)hipGetLastError();                                                                \
+			return cs_fail_(e__ == hipErrorOutOfMemory ? CS_ENOMEM : CS_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+		}                                                                                           \
+	} while (0)
+
+namespace cse {
+
+constexpr int NEG = -0x40000000; // identity of max for scores (|score| < 2^30: checked on the host)
+
+// ---- cross-lane primitives (gfx9 DPP: row shifts inside the four rows of 16 lanes, then row broadcasts to combine the rows)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_take(int keep, int v) { return __builtin_amdgcn_update_dpp(keep, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_scan_max(int v) // inclusive: lane l gets max(v[0..l])
+{
+	v = imax(v, dpp_take<0x111, 0xf>(NEG, v)); // row_shr:1
+	v = imax(v, dpp_take<0x112, 0xf>(NEG, v)); // row_shr:2
+	v = imax(v, dpp_take<0x114, 0xf>(NEG, v)); // row_shr:4
+	v = imax(v, dpp_take<0x118, 0xf>(NEG, v)); // row_shr:8
+	v = imax(v, dpp_take<0x142, 0xa>(NEG, v)); // row_bcast:15 into rows 1 and 3
+	v = imax(v, dpp_take<0x143, 0xc>(NEG, v)); // row_bcast:31 into rows 2 and 3
+	return v;
+}
+__device__ __forceinline__ int wave_shift_up(int v, int lane0) { return dpp_take<0x138, 0xf>(lane0, v); } // lane l gets v[l-1], lane 0 gets lane0 (wave_shr:1)
+
+struct ExtParams { int32_t match, mismatch, o_del, e_del, o_ins, e_ins, zdrop, end_bonus, best; }; // match / mismatch = mat[0] / mat[1]; best = largest matrix entry
+
+struct ExtArgs {
+	const cs_ext_pair_t *pairs; int64_t n;
+	const uint8_t *qbuf, *tbuf; uint64_t q_bytes, t_bytes;
+	cs_ext_result_t *out;
+	int32_t w, max_qlen;
+	ExtParams P;
+	const int8_t *mat;                 // the 5 x 5 matrix in device memory (read by the scalar rule only)
+	int32_t *scratch;                  // HBM variant: (max_qlen + 2) x 2 ints per wave
+	unsigned long long *err;           // pairs whose offsets leave the buffers / qlen < 1 (skipped, result zeroed)
+	unsigned long long *stat;          // [0] DP cells computed, [1] rows
+};
+
+// the scoring rule (oracle/cs_bsw_oracle.c states both): the reference's vectorised code compares codes (mapping/bandedSWA.cpp:286-290),
+// its scalar code -- used for pairs of 32768 bases or more, comp_seed.cpp:1569-1577 -- indexes the matrix (ksw.c:392-395)
+__device__ __forceinline__ int pair_score(const ExtParams &P, const int8_t *mat, bool vec_rule, int t, int q)
+{
+	if (vec_rule) return (t == 4 || q == 4) ? -1 : (t == q ? P.match : P.mismatch);
+	const int k = 5 * t + q;
+	return k < 25 ? (int)mat[k] : 0; // (a code-5 query base against target code 4 reads past the reference's matrix: undefined there, 0 here)
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void extend_kernel(const ExtArgs A)
+{
+	extern __shared__ int32_t smem[];
+	// (readfirstlane: the wave number is the same in all 64 lanes, and telling the compiler so keeps everything derived from it -- the pair,
+	// the row loop, the band -- in scalar registers)
+	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
+	const int64_t wave = (int64_t)blockIdx.x * wpb + wv, n_waves = (int64_t)gridDim.x * wpb;
+	const int cols = A.max_qlen + 2;
+	int32_t *Hd, *Ev; uint8_t *qs = nullptr;
+	if (LDS) { // per wave: Hd[cols], Ev[cols], then the query bytes
+		const int per_wave = 2 * cols + ((A.max_qlen + 3) >> 2);
+		Hd = smem + (size_t)wv * per_wave; Ev = Hd + cols; qs = reinterpret_cast<uint8_t *>(Ev + cols);
+	} else { Hd = A.scratch + (size_t)wave * 2 * cols; Ev = Hd + cols; }
+	const ExtParams &P = A.P;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_ins = P.e_ins, e_del = P.e_del;
+	unsigned long long my_cells = 0, my_rows = 0;
+	for (int64_t p = wave; p < A.n; p += n_waves) { // wave-uniform
+		const cs_ext_pair_t pr = A.pairs[p];
+		const int qlen = pr.qlen, tlen = pr.tlen, h0 = pr.h0;
+		if (qlen < 1 || tlen < 0 || qlen > A.max_qlen || pr.q_off > A.q_bytes || (uint64_t)qlen > A.q_bytes - pr.q_off || pr.t_off > A.t_bytes ||
+		    (uint64_t)tlen > A.t_bytes - pr.t_off) {
+			if (lane == 0) { atomicAdd(A.err, 1ull); cs_ext_result_t z = {0, 0, 0, 0, 0, 0}; A.out[p] = z; }
+			continue;
+		}
+		const uint8_t *qg = A.qbuf + pr.q_off, *tg = A.tbuf + pr.t_off;
+		const bool vec_rule = qlen < 32768 && tlen < 32768 && h0 + (qlen < tlen ? qlen : tlen) * P.match < 32768;
+		// ---- row "-1" (ksw.c:398-400): the seed's score decays along the query by one insertion; both arrays cleared
+		const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
+		for (int j = lane; j <= qlen + 1; j += 64) {
+			Hd[j] = j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0;
+			Ev[j] = 0;
+		}
+		if (LDS) for (int j = lane; j < qlen; j += 64) qs[j] = qg[j];
+		// ---- the band cannot usefully be wider than the longest gap the best possible score pays for (ksw.c:402-410)
+		int w = A.w;
+		{
+			int lim = (int)((double)(qlen * P.best + P.end_bonus - P.o_ins) / (double)e_ins + 1.);
+			lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+			lim = (int)((double)(qlen * P.best + P.end_bonus - P.o_del) / (double)e_del + 1.);
+			lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+		}
+		__builtin_amdgcn_wave_barrier();
+		int top = h0, top_i = -1, top_j = -1, g_best = -1, g_row = -1, off = 0, beg = 0, end = qlen;
+		int tv = 4; // target bases i0 .. i0 + 63, one per lane
+		for (int i = 0; i < tlen; ++i) { // wave-uniform
+			if ((i & 63) == 0) tv = i + lane < tlen ? (int)tg[i + lane] : 4;
+			const int ti = __builtin_amdgcn_readlane(tv, i & 63);
+			if (beg < i - w) beg = i - w;
+			if (end > i + w + 1) end = i + w + 1;
+			if (end > qlen) end = qlen;
+			const int left = beg == 0 ? imax(h0 - (P.o_del + e_del * (i + 1)), 0) : 0; // H(i, beg - 1) (ksw.c:419-423)
+			int row_max = 0, row_arg = -1, hcarry = left, fcarry = 0, hlast = left, first_nz = 0x7fffffff, last_nz = -1;
+			for (int cb = beg; cb < end; cb += 64) { // wave-uniform: 64 columns at a time
+				const int j = cb + lane; const bool act = j < end;
+				const int hd = act ? Hd[j] : 0, ev = act ? Ev[j] : 0;
+				const int qj = act ? (LDS ? (int)qs[j] : (int)qg[j]) : 4;
+				const int M = hd ? hd + pair_score(P, A.mat, vec_rule, ti, qj) : 0;        // a path may not restart from a zero cell (ksw.c:436)
+				const int g = act ? imax(M - oe_ins, 0) : NEG;
+				// F: exclusive max-scan of g(k) + k e_ins, and the carry from the chunks to the left decaying by e_ins per column
+				const int incl = wave_scan_max(act ? g + lane * e_ins : NEG);
+				const int excl = wave_shift_up(incl, NEG);
+				int F = imax(fcarry - lane * e_ins, excl - (lane - 1) * e_ins);
+				if (lane == 0) F = fcarry;
+				const int h = imax(imax(M, ev), F);
+				const int hprev = wave_shift_up(h, hcarry);                       // H(i, j-1): the diagonal of column j in the next row
+				const int evn = imax(ev - e_del, imax(M - oe_del, 0));
+				if (act) { Hd[j] = hprev; Ev[j] = evn; }
+				// row maximum and the LAST column that reaches it (ksw.c:440-441)
+				const int hm = act ? h : -1;
+				const int cm = __builtin_amdgcn_readlane(wave_scan_max(hm), 63);
+				if (cm >= row_max) { row_max = cm; row_arg = cb + 63 - __builtin_clzll(__ballot(hm == cm)); }
+				// live columns for the adaptive band (ksw.c:470-473 look at the arrays as this row leaves them)
+				const unsigned long long nzm = __ballot(act && (hprev | evn) != 0);
+				if (nzm) { if (first_nz == 0x7fffffff) first_nz = cb + __builtin_ctzll(nzm); last_nz = cb + 63 - __builtin_clzll(nzm); }
+				const int nact = end - cb < 64 ? end - cb : 64;
+				hlast = __builtin_amdgcn_readlane(h, nact - 1);
+				hcarry = hlast;
+				fcarry = __builtin_amdgcn_readlane(imax(F - e_ins, g), 63);        // F at the first column of the next chunk
+				my_cells += (unsigned)nact;
+			}
+			if (lane == 0) { Hd[end] = hlast; Ev[end] = 0; }
+			__builtin_amdgcn_wave_barrier();
+			++my_rows;
+			if ((beg < end ? end : beg) == qlen) { // the row reached the end of the query (ksw.c:452-455)
+				if (!(g_best > hlast)) g_row = i;
+				g_best = imax(g_best, hlast);
+			}
+			if (row_max == 0) break;
+			if (row_max > top) {
+				top = row_max; top_i = i; top_j = row_arg;
+				const int d = row_arg - i; off = imax(off, d < 0 ? -d : d);
+			} else if (P.zdrop > 0) { // Z-drop with the diagonal shift priced as a gap extension (ksw.c:461-467)
+				const int di = i - top_i, dj = row_arg - top_j;
+				if (di > dj) { if (top - row_max - (di - dj) * e_del > P.zdrop) break; }
+				else if (top - row_max - (dj - di) * e_ins > P.zdrop) break;
+			}
+			const int nbeg = first_nz < end ? first_nz : end;
+			const int jz = hlast != 0 ? end : (last_nz >= nbeg ? last_nz : nbeg - 1);
+			beg = nbeg; end = jz + 2 < qlen ? jz + 2 : qlen;
+		}
+		if (lane == 0) { cs_ext_result_t r = {top, top_j + 1, top_i + 1, g_row + 1, g_best, off}; A.out[p] = r; }
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (lane == 0 && A.stat) { atomicAdd(A.stat, my_cells); atomicAdd(A.stat + 1, my_rows); }
+}
+
+__global__ void max_qlen_kernel(const cs_ext_pair_t *pairs, int64_t n, unsigned long long *out)
+{
+	unsigned long long m = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int q = pairs[i].qlen; if (q > 0 && (unsigned long long)q > m) m = (unsigned long long)q; }
+	for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(m, o); m = x > m ? x : m; }
+	if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+} // namespace cse
+
+struct cs_extender {
+	int device = 0, n_cu = 256;
+	cse::ExtParams P{};
+	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	void *d_pairs = nullptr, *d_q = nullptr, *d_t = nullptr, *d_out = nullptr, *d_scratch = nullptr; size_t c_pairs = 0, c_q = 0, c_t = 0, c_out = 0, c_scratch = 0;
+	unsigned long long *d_ctr = nullptr, *h_ctr = nullptr; // device words: [0] skipped pairs [1] cells [2] rows [3] longest query; [4..7] hold the matrix
+	cs_ext_stats_t st{};
+};
+
+static int grow(void **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return CS_OK;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr; *cap = 0;
+	const size_t want = need + need / 4 + 256;
+	HIP_TRYX(hipMalloc(p, want));
+	*cap = want;
+	return CS_OK;
+}
+
+extern "C" void cs_ext_params_default(cs_ext_params_t *p)
+{
+	if (!p) return;
+	// mem_opt_init (mapping/comp_seed.cpp:26-58): a = 1, b = 4, o_del = o_ins = 6, e_del = e_ins = 1, zdrop = 100, pen_clip5 = pen_clip3 = 5; bwa_fill_scmat (bwalib/bwa.c:17-29)
+	for (int i = 0, k = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) p->mat[k++] = (int8_t)(i == 4 || j == 4 ? -1 : i == j ? 1 : -4);
+	p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1; p->zdrop = 100; p->end_bonus = 5;
+}
+
+extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_extender_t **out)
+{
+	if (!out) return cs_fail_(CS_EINVAL, "cs_extender_create: null argument");
+	*out = nullptr;
+	cs_ext_params_t dp;
+	if (!par) { cs_ext_params_default(&dp); par = &dp; }
+	if (par->e_del < 1 || par->e_ins < 1 || par->o_del < 0 || par->o_ins < 0 || par->zdrop < 0) return cs_fail_(CS_EINVAL, "cs_extender_create: gap extension penalties must be positive, gap opens and zdrop non-negative");
+	int ndev = 0;
+	HIP_TRYX(hipGetDeviceCount(&ndev));
+	if (ndev <= 0) return cs_fail_(CS_EDEVICE, "no HIP device: the extension kernel has no CPU path");
+	if (device < 0 || device >= ndev) return cs_fail_(CS_EINVAL, "device ordinal out of range");
+	HIP_TRYX(hipSetDevice(device));
+	cs_extender *x = new cs_extender();
+	x->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) x->n_cu = prop.multiProcessorCount;
+	x->P.match = par->mat[0]; x->P.mismatch = par->mat[1];
+	x->P.o_del = par->o_del; x->P.e_del = par->e_del; x->P.o_ins = par->o_ins; x->P.e_ins = par->e_ins; x->P.zdrop = par->zdrop; x->P.end_bonus = par->end_bonus;
+	x->P.best = 0;
+	for (int k = 0; k < 25; ++k) x->P.best = std::max<int>(x->P.best, par->mat[k]);
+	hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreate(&x->ev0);
+	if (e == hipSuccess) e = hipEventCreate(&x->ev1);
+	if (e == hipSuccess) e = hipMalloc((void **)&x->d_ctr, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_ctr, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipMemcpy(x->d_ctr + 4, par->mat, 25, hipMemcpyHostToDevice);
+	if (e != hipSuccess) { (void)hipGetLastError(); cs_extender_destroy(x); return cs_fail_(CS_EDEVICE, std::string("cs_extender_create: ") + hipGetErrorString(e)); }
+	*out = x;
+	return CS_OK;
+}
+
+extern "C" void cs_extender_destroy(cs_extender_t *x)
+{
+	if (!x) return;
+	(void)hipSetDevice(x->device);
+	if (x->stream) (void)hipStreamSynchronize(x->stream);
+	for (void *p : {x->d_pairs, x->d_q, x->d_t, x->d_out, x->d_scratch, (void *)x->d_ctr}) if (p) (void)hipFree(p);
+	if (x->h_ctr) (void)hipHostFree(x->h_ctr);
+	if (x->ev0) (void)hipEventDestroy(x->ev0);
+	if (x->ev1) (void)hipEventDestroy(x->ev1);
+	if (x->stream) (void)hipStreamDestroy(x->stream);
+	delete x;
+}
+
+// the launch: pairs, sequences and results are device memory here
+static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs, const uint8_t *d_q, uint64_t q_bytes, const uint8_t *d_t, uint64_t t_bytes,
+                         int32_t w, cs_ext_result_t *d_out)
+{
+	hipStream_t s = x->stream;
+	HIP_TRYX(hipMemsetAsync(x->d_ctr, 0, 4 * sizeof(unsigned long long), s));
+	hipLaunchKernelGGL(cse::max_qlen_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)x->n_cu * 8)), dim3(256), 0, s, d_pairs, n, x->d_ctr + 3);
+	HIP_TRYX(hipGetLastError());
+	HIP_TRYX(hipMemcpyAsync(x->h_ctr, x->d_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRYX(hipStreamSynchronize(s));
+	const int64_t max_q = (int64_t)x->h_ctr[3];
+	if (max_q > 65535) return cs_fail_(CS_ERANGE, "cs_extend_batch: a query is longer than 65535 bases (MAX_READ_LEN, mapping/comp_seed.h:39)");
+	if ((int64_t)x->P.best * max_q > (1 << 29)) return cs_fail_(CS_ERANGE, "cs_extend_batch: scores would not fit the kernel's 30-bit range");
+	cse::ExtArgs A;
+	A.pairs = d_pairs; A.n = n; A.qbuf = d_q; A.tbuf = d_t; A.q_bytes = q_bytes; A.t_bytes = t_bytes; A.out = d_out; A.w = w; A.max_qlen = (int32_t)std::max<int64_t>(max_q, 1);
+	A.P = x->P; A.mat = (const int8_t *)(x->d_ctr + 4); A.scratch = nullptr; A.err = x->d_ctr; A.stat = x->d_ctr + 1;
+	const size_t per_wave = ((size_t)2 * (A.max_qlen + 2) + ((A.max_qlen + 3) >> 2)) * 4; // bytes of LDS per wave
+	HIP_TRYX(hipEventRecord(x->ev0, s));
+	if (per_wave <= 60 * 1024) {
+		const int wpb = per_wave <= 15 * 1024 ? 4 : per_wave <= 30 * 1024 ? 2 : 1;
+		const int64_t blocks = std::min<int64_t>((n + wpb - 1) / wpb, (int64_t)x->n_cu * (wpb == 4 ? 8 : wpb == 2 ? 4 : 2));
+		hipLaunchKernelGGL(cse::extend_kernel<true>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(64 * wpb), per_wave * wpb, s, A);
+	} else { // long queries: the band state in HBM
+		const int64_t blocks = std::min<int64_t>((n + 3) / 4, (int64_t)x->n_cu * 4);
+		if (int rc = grow(&x->d_scratch, &x->c_scratch, (size_t)std::max<int64_t>(blocks, 1) * 4 * 2 * (A.max_qlen + 2) * sizeof(int32_t))) return rc;
+		A.scratch = (int32_t *)x->d_scratch;
+		hipLaunchKernelGGL(cse::extend_kernel<false>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, s, A);
+	}
+	HIP_TRYX(hipGetLastError());
+	HIP_TRYX(hipEventRecord(x->ev1, s));
+	HIP_TRYX(hipMemcpyAsync(x->h_ctr, x->d_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRYX(hipStreamSynchronize(s));
+	float ms = 0.f;
+	HIP_TRYX(hipEventElapsedTime(&ms, x->ev0, x->ev1));
+	x->st.pairs += (uint64_t)n; x->st.cells += x->h_ctr[1]; x->st.rows += x->h_ctr[2]; x->st.kernel_ms += ms; x->st.launches++;
+	if (x->h_ctr[0]) return cs_fail_(CS_EINVAL, "cs_extend_batch: " + std::to_string(x->h_ctr[0]) + " pair(s) with qlen < 1, tlen < 0 or offsets outside the sequence buffers (their results are zero)");
+	return CS_OK;
+}
+
+extern "C" int cs_extend_batch_device(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *d_pairs, const uint8_t *d_qbuf, uint64_t q_bytes,
+                                      const uint8_t *d_tbuf, uint64_t t_bytes, int32_t w, cs_ext_result_t *d_out)
+{
+	if (!x || n_pairs < 0 || w < 0 || (n_pairs > 0 && (!d_pairs || !d_out))) return cs_fail_(CS_EINVAL, "cs_extend_batch_device: bad argument");
+	if (n_pairs == 0) return CS_OK;
+	HIP_TRYX(hipSetDevice(x->device));
+	return extend_device(x, n_pairs, d_pairs, d_qbuf, q_bytes, d_tbuf, t_bytes, w, d_out);
+}
+
+extern "C" int cs_extend_batch(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *pairs, const uint8_t *qbuf, uint64_t q_bytes,
+                               const uint8_t *tbuf, uint64_t t_bytes, int32_t w, cs_ext_result_t *out)
+{
+	if (!x || n_pairs < 0 || w < 0 || (n_pairs > 0 && (!pairs || !out)) || (q_bytes && !qbuf) || (t_bytes && !tbuf)) return cs_fail_(CS_EINVAL, "cs_extend_batch: bad argument");
+	if (n_pairs == 0) return CS_OK;
+	HIP_TRYX(hipSetDevice(x->device));
+	if (int rc = grow(&x->d_pairs, &x->c_pairs, (size_t)n_pairs * sizeof(cs_ext_pair_t))) return rc;
+	if (int rc = grow(&x->d_out, &x->c_out, (size_t)n_pairs * sizeof(cs_ext_result_t))) return rc;
+	if (int rc = grow(&x->d_q, &x->c_q, (size_t)q_bytes + 64)) return rc;
+	if (int rc = grow(&x->d_t, &x->c_t, (size_t)t_bytes + 64)) return rc;
+	hipStream_t s = x->stream;
+	HIP_TRYX(hipMemcpyAsync(x->d_pairs, pairs, (size_t)n_pairs * sizeof(cs_ext_pair_t), hipMemcpyHostToDevice, s));
+	if (q_bytes) HIP_TRYX(hipMemcpyAsync(x->d_q, qbuf, (size_t)q_bytes, hipMemcpyHostToDevice, s));
+	if (t_bytes) HIP_TRYX(hipMemcpyAsync(x->d_t, tbuf, (size_t)t_bytes, hipMemcpyHostToDevice, s));
+	const int rc = extend_device(x, n_pairs, (const cs_ext_pair_t *)x->d_pairs, (const uint8_t *)x->d_q, q_bytes, (const uint8_t *)x->d_t, t_bytes, w, (cs_ext_result_t *)x->d_out);
+	const std::string keep = rc != CS_OK ? std::string(cs_last_error()) : std::string();
+	if (rc == CS_OK || rc == CS_EINVAL) { // (CS_EINVAL from skipped pairs: the other results are valid and are delivered)
+		hipError_t e = hipMemcpyAsync(out, x->d_out, (size_t)n_pairs * sizeof(cs_ext_result_t), hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess) e = hipStreamSynchronize(s);
+		if (e != hipSuccess) { (void)hipGetLastError(); return cs_fail_(CS_EDEVICE, hipGetErrorString(e)); }
+	}
+	if (rc != CS_OK) return cs_fail_(rc, keep);
+	return CS_OK;
+}
+
+extern "C" int cs_extender_stats(const cs_extender_t *x, cs_ext_stats_t *st)
+{
+	if (!x || !st) return cs_fail_(CS_EINVAL, "null argument");
+	*st = x->st;
+	return CS_OK;
+}

@@ -275,6 +275,36 @@ void cs_chain_params_default(cs_chain_params_t *p);
 int  cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, const cs_result_t *seeds, const uint64_t *read_offsets, int n_threads,
                     cs_chain_result_t *out);
 
+/* ---- seed extension: the banded Smith-Waterman extensions of mem_chain2aln_across_reads_V2 (mapping/comp_seed.cpp:1319), i.e.
+ *      what the reference hands to BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (mapping/bandedSWA.h:117-167; call sites
+ *      comp_seed.cpp:1719,1790,1859,1942,2003,2074), computed on the GPU with the exact semantics of ksw_extend2 (bwalib/ksw.c:380-479): band of
+ *      +-w diagonals that shrinks to the live columns, Z-drop, end bonus in the band limit only.  A cs_extender_t corresponds to a
+ *      BandedPairWiseSW object (its constructor's parameters, bandedSWA.h:117-121); cs_ext_pair_t to the input fields of SeqPair (idq, idr,
+ *      len2, len1, h0; bandedSWA.h:90-100) with 64-bit offsets into the two sequence buffers (codes 0..4, one byte per base; the query and
+ *      target of a left extension reversed by the caller as comp_seed.cpp:1525,1546 do); cs_ext_result_t to its output fields.  All pairs of
+ *      a call share the band width w (the reference calls once per band try: w, then 2w for the pairs whose max_off came close to the band,
+ *      comp_seed.cpp:1740-1742).  Scoring: pairs the reference would send to its vectorised code (both lengths and h0 + min(len) * match
+ *      below 32768, comp_seed.cpp:1569-1577) compare base codes -- ambiguous (4) on either side scores -1, equal codes mat[0], others mat[1]
+ *      (bandedSWA.cpp:286-290) -- longer ones index the 5 x 5 matrix like ksw_extend2; the two only differ for codes above 4.
+ *      Known deviation of the REFERENCE from its own definition, not reproduced: its vectorised code gives other numbers than ksw_extend2
+ *      in a few pairs per thousand when o_del != o_ins or a gap extension is not 1 (tests/test_oracle_bsw.py); this library computes
+ *      ksw_extend2's result for every parameter set.  Host variant: host pointers in, results in `out`; device variant: everything is device
+ *      memory on the extender's GPU.  Pairs with qlen < 1, tlen < 0 or offsets outside the buffers get a zero result and the call returns
+ *      CS_EINVAL after delivering the others. */
+typedef struct { int8_t mat[25]; int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus; } cs_ext_params_t;
+typedef struct { uint64_t q_off, t_off; int32_t qlen, tlen, h0, reserved; } cs_ext_pair_t;
+typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } cs_ext_result_t;
+typedef struct { uint64_t pairs, cells, rows, launches; double kernel_ms; } cs_ext_stats_t;   /* cells = DP cells computed (inside the adaptive band) */
+typedef struct cs_extender cs_extender_t;
+void cs_ext_params_default(cs_ext_params_t *p);               /* mem_opt_init's scoring: a 1, b 4, o 6, e 1, zdrop 100, pen_clip 5 (comp_seed.cpp:26-58) */
+int  cs_extender_create(int device, const cs_ext_params_t *par /* NULL: defaults */, cs_extender_t **out);
+void cs_extender_destroy(cs_extender_t *x);
+int  cs_extend_batch(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *pairs, const uint8_t *qbuf, uint64_t q_bytes,
+                     const uint8_t *tbuf, uint64_t t_bytes, int32_t w, cs_ext_result_t *out);
+int  cs_extend_batch_device(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *d_pairs, const uint8_t *d_qbuf, uint64_t q_bytes,
+                            const uint8_t *d_tbuf, uint64_t t_bytes, int32_t w, cs_ext_result_t *d_out);
+int  cs_extender_stats(const cs_extender_t *x, cs_ext_stats_t *st);
+
 /* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array
  *      (sum over the array's 64-bit words w[i] of splitmix64(w[i] + i * 0x9E3779B97F4A7C15), mod 2^64), so that two runs over
  *      10 M reads can be compared word for word without downloading 6 GB; and the CSR slice of selected reads (any order,

@@ -29,6 +29,14 @@ int main(int argc, char **argv)
 	FILE *fp = fopen(argv[1], "wb");
 	if (!fp) { perror(argv[1]); return 1; }
 	fwrite("CSBSW01", 1, 8, fp); fwrite(mat, 1, 25, fp);
+	// a menu of parameter sets (so that a consumer can group the records into a few dozen objects): set 0 = mem_opt_init's scoring
+	struct Set { int o_del, e_del, o_ins, e_ins, zdrop, end_bonus; };
+	const int N_SETS = 20;
+	Set menu[N_SETS];
+	menu[0] = Set{6, 1, 6, 1, 100, 5};
+	for (int k = 1; k < N_SETS; ++k)
+		menu[k] = Set{rin(1, 2) == 1 ? rin(1, 10) : 6, rin(1, 3) == 1 ? rin(2, 3) : 1, rin(1, 2) == 1 ? rin(1, 10) : 6, rin(1, 3) == 1 ? rin(2, 3) : 1,
+		              k % 4 == 0 ? 0 : rin(1, 2) == 1 ? rin(1, 30) : 100, rin(0, 1) ? 5 : rin(0, 20)};
 	for (long it = 0; it < n; ++it) {
 		const int qlen = (it % 50 == 0) ? rin(150, 400) : rin(1, 140);
 		std::vector<uint8_t> q((size_t)qlen), t;
@@ -50,9 +58,10 @@ int main(int argc, char **argv)
 		if (rin(1, 12) == 1) q[(size_t)rin(0, qlen - 1)] = 4;
 		if (it % 97 == 0) t.clear();
 		const int tlen = (int)t.size();
-		const int o_del = rin(1, 3) == 1 ? rin(1, 10) : 6, e_del = rin(1, 4) == 1 ? rin(1, 3) : 1, o_ins = rin(1, 3) == 1 ? rin(1, 10) : 6, e_ins = rin(1, 4) == 1 ? rin(1, 3) : 1;
-		const int w = rin(1, 3) == 1 ? rin(1, 40) : rin(1, 2) == 1 ? 100 : 200;
-		const int zdrop = rin(1, 5) == 1 ? 0 : rin(1, 3) == 1 ? rin(1, 30) : 100, end_bonus = rin(0, 1) ? 5 : rin(0, 20);
+		const Set &ps = menu[rin(1, 3) == 1 ? 0 : rin(1, N_SETS - 1)];
+		const int o_del = ps.o_del, e_del = ps.e_del, o_ins = ps.o_ins, e_ins = ps.e_ins, zdrop = ps.zdrop, end_bonus = ps.end_bonus;
+		static const int bands[8] = {1, 3, 8, 21, 40, 100, 100, 200};
+		const int w = bands[rin(0, 7)];
 		const int h0 = rin(1, 4) == 1 ? rin(1, 10) : rin(19, 150) * a;
 		int qle = 0, tle = 0, gtle = 0, gscore = 0, max_off = 0;
 		const int score = ksw_extend2(qlen, q.data(), tlen, t.data(), 5, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0, &qle, &tle, &gtle, &gscore, &max_off);
