@@ -76,6 +76,7 @@ def parse_args():
     ap.add_argument("--side-workloads", default="repeat50",
                     help="comma-separated workload profiles measured after the headline in a child run of this script (N = 1 only; '' = none): "
                          "reported under `workloads`, never part of `value`")
+    ap.add_argument("--no-extension", action="store_true", help="skip the seed-extension side measurement (`extension` key)")
     ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)  # internal: a child run for `workloads`
     ap.add_argument("--index-broadcast", action="store_true",
                     help="N > 1: rank 0 builds the index and broadcasts it over RCCL instead of every rank building its own replica")
@@ -564,6 +565,19 @@ def main():
         del big, g_
     oidx.close()
     eng.close(); ix.close()
+    if rank == 0 and world == 1 and not args.side_child and not args.pmc_child and not args.no_extension:
+        # ---- SURVEY 8f row 4, the stage behind seeding + chaining: banded Smith-Waterman seed extension on the GPU (tools/extend_bench.py);
+        # integer-compute-bound, so pairs/s and DP cells/s, not a fraction of HBM bandwidth; never part of `value`
+        try:
+            import extend_bench
+            out["extension"] = extend_bench.run(cpu_threads=min(16, cpu_quota()[0]), device=local)
+            if not out["extension"]["bit_exact_vs_oracle"]:
+                all_ok = False
+                out["value"] = None
+                out["error"] = "extension kernel: results differ from the oracle"
+        except Exception as ex:  # noqa: BLE001
+            log("extension side measurement failed: %r" % (ex,))
+            out["extension"] = {"error": repr(ex)[:300]}
     side = [w for w in args.side_workloads.split(",") if w and w != args.profile]
     if rank == 0 and world == 1 and side and not args.side_child and not args.pmc_child:
         # ---- the same measurement on other workload profiles (tools/synth.py), outside the headline: a child run of this script per
@@ -573,7 +587,7 @@ def main():
         out["workloads"] = {}
         for w in side:
             cmd = [sys.executable, os.path.abspath(__file__), "--side-child", "--profile", w, "--steps", "3", "--warmup", "1", "--traffic", "none",
-                   "--cpu-seconds", "0", "--no-host-io", "--genome-mbp", str(args.genome_mbp), "--reads", str(args.reads), "--read-len", str(args.read_len),
+                   "--cpu-seconds", "0", "--no-host-io", "--no-extension", "--genome-mbp", str(args.genome_mbp), "--reads", str(args.reads), "--read-len", str(args.read_len),
                    "--check-reads", str(args.check_reads), "-k", str(args.k), "-r", str(args.r), "-y", str(args.y), "-c", str(args.c), "-s", str(args.s)]
             if args.lib:
                 cmd += ["--lib", args.lib]

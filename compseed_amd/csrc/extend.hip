@@ -47,12 +47,17 @@ __device__ __forceinline__ int dpp_take(int keep, int v) { return __builtin_amdg
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int wave_scan_max(int v) // inclusive: lane l gets max(v[0..l])
 {
-	v = imax(v, dpp_take<0x111, 0xf>(NEG, v)); // row_shr:1
-	v = imax(v, dpp_take<0x112, 0xf>(NEG, v)); // row_shr:2
-	v = imax(v, dpp_take<0x114, 0xf>(NEG, v)); // row_shr:4
-	v = imax(v, dpp_take<0x118, 0xf>(NEG, v)); // row_shr:8
-	v = imax(v, dpp_take<0x142, 0xa>(NEG, v)); // row_bcast:15 into rows 1 and 3
-	v = imax(v, dpp_take<0x143, 0xc>(NEG, v)); // row_bcast:31 into rows 2 and 3
+	// Six v_max_i32_dpp in place: a lane without a source (row start, rows a broadcast does not address) is simply not written and keeps its
+	// own value.  Written as assembly because the compiler emits identity move + DPP move + max per step (this scan runs twice per 64 DP
+	// cells and the kernel is VALU-bound); the s_nop are the two wait states a DPP read needs behind a VALU write of the same register.
+	asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	             "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+	             "s_nop 1"
+	             : "+v"(v));
 	return v;
 }
 __device__ __forceinline__ int wave_shift_up(int v, int lane0) { return dpp_take<0x138, 0xf>(lane0, v); } // lane l gets v[l-1], lane 0 gets lane0 (wave_shr:1)
@@ -81,7 +86,7 @@ __device__ __forceinline__ int pair_score(const ExtParams &P, const int8_t *mat,
 }
 
 template <bool LDS>
-__global__ __launch_bounds__(256) void extend_kernel(const ExtArgs A)
+__global__ __launch_bounds__(256, 8) void extend_kernel(const ExtArgs A)
 {
 	extern __shared__ int32_t smem[];
 	// (readfirstlane: the wave number is the same in all 64 lanes, and telling the compiler so keeps everything derived from it -- the pair,
@@ -135,9 +140,12 @@ __global__ __launch_bounds__(256) void extend_kernel(const ExtArgs A)
 			int row_max = 0, row_arg = -1, hcarry = left, fcarry = 0, hlast = left, first_nz = 0x7fffffff, last_nz = -1;
 			for (int cb = beg; cb < end; cb += 64) { // wave-uniform: 64 columns at a time
 				const int j = cb + lane; const bool act = j < end;
-				const int hd = act ? Hd[j] : 0, ev = act ? Ev[j] : 0;
-				const int qj = act ? (LDS ? (int)qs[j] : (int)qg[j]) : 4;
-				const int M = hd ? hd + pair_score(P, A.mat, vec_rule, ti, qj) : 0;        // a path may not restart from a zero cell (ksw.c:436)
+				const int jc = act ? j : end - 1;                                  // (every lane loads: no branch around three LDS reads)
+				const int hd = Hd[jc], ev = act ? Ev[jc] : 0;
+				const int qj = LDS ? (int)qs[jc] : (int)qg[jc];
+				int sc = (qj == 4 || ti == 4) ? -1 : (qj == ti ? P.match : P.mismatch);
+				if (!vec_rule) { const int k = 5 * ti + qj; sc = k < 25 ? (int)A.mat[k] : 0; } // (wave-uniform branch; pairs of 32768 bases or more only)
+				const int M = (act && hd != 0) ? hd + sc : 0;                       // a path may not restart from a zero cell (ksw.c:436)
 				const int g = act ? imax(M - oe_ins, 0) : NEG;
 				// F: exclusive max-scan of g(k) + k e_ins, and the carry from the chunks to the left decaying by e_ins per column
 				const int incl = wave_scan_max(act ? g + lane * e_ins : NEG);

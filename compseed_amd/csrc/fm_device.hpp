@@ -59,9 +59,17 @@ enum : int { KID_FWD0 = 0, KID_FWD, KID_BWD_WIN, KID_BWD_WIN0, KID_BWD_WIDE, KID
 template <bool ON> struct WaveCtrT;
 template <> struct WaveCtrT<true> {
 	uint32_t v[N_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                               // this LANE's events
+#ifdef CS_X2_HIST // experiment build (make variant DEFS=-DCS_X2_HIST): the ten event slots hold a histogram of the interval sizes extend1 is asked for
+	__device__ __forceinline__ void add(int, uint32_t) {}
+	__device__ __forceinline__ void addn(int, uint32_t) {}
+	__device__ __forceinline__ void rec(bool) {}
+	__device__ __forceinline__ void hist(uint32_t x2) { v[x2 <= 1 ? 0 : x2 <= 2 ? 1 : x2 <= 4 ? 2 : x2 <= 8 ? 3 : x2 <= 16 ? 4 : x2 <= 64 ? 5 : x2 <= 256 ? 6 : x2 <= 4096 ? 7 : x2 <= 65536 ? 8 : 9] += 1u; }
+#else
 	__device__ __forceinline__ void add(int ev, uint32_t n) { v[ev] += n; }
 	__device__ __forceinline__ void addn(int ev, uint32_t n) { v[ev] += n; }
 	__device__ __forceinline__ void rec(bool two) { v[EV_REC] += two ? 2u : 1u; }
+	__device__ __forceinline__ void hist(uint32_t) {}
+#endif
 	__device__ __forceinline__ void flush(unsigned long long *evc, int kid) const                    // every lane of the wave must call it
 	{
 		for (int ev = 0; ev < N_EV; ++ev) {
@@ -75,6 +83,7 @@ template <> struct WaveCtrT<false> {
 	__device__ __forceinline__ void add(int, uint32_t) {}
 	__device__ __forceinline__ void addn(int, uint32_t) {}
 	__device__ __forceinline__ void rec(bool) {}
+	__device__ __forceinline__ void hist(uint32_t) {}
 	__device__ __forceinline__ void flush(unsigned long long *, int) const {}
 };
 using WaveCtr = WaveCtrT<true>;
@@ -220,6 +229,7 @@ __device__ __forceinline__ Intv extend1(const DevIndex &ix, const Intv &ik, int 
 	// two still travel together; nothing waits until the first use below.
 	const bool two = (rk >> OCC_SHIFT) != (rl >> OCC_SHIFT);
 	W.rec(two); // records requested: one per lane, two where the rows straddle
+	W.hist(ik.x2);
 	Block bk = load_block(ix, rk >> OCC_SHIFT);
 	Block b2;
 	if (two) b2 = load_block(ix, rl >> OCC_SHIFT);

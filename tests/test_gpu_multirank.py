@@ -30,7 +30,7 @@ def _run_two_ranks(extra):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dist-backend", "gloo", "--genome-mbp", "200",
-               "--reads", "500000", "--check-reads", "5000", "--traffic", "none", "--cpu-seconds", "0", "--no-host-io", "--side-workloads", ""] + extra
+               "--reads", "500000", "--check-reads", "5000", "--traffic", "none", "--cpu-seconds", "0", "--no-host-io", "--side-workloads", "", "--no-extension"] + extra
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):

@@ -215,12 +215,57 @@ def test_many_exact_long_reads_overflow_records(world, sst):
     assert int(np.diff(want["mem_off"].astype(np.int64)).max()) > 64
 
 
+def test_repeat_rich_and_indel_workloads_at_500mbp():
+    """The unfriendly end of the workload range (tools/synth.py profiles; a real hg19 is ~50 % repeats, mostly old, diverged copies) in the
+    driver-run tests: a 500 Mbp genome with five interspersed families at 2-25 % divergence and satellite arrays (`repeat50`), and 2 M reads each
+    of three kinds -- 0.5 % substitutions, 1 % substitutions + 0.1 %/base indels, 2 % substitutions + indels.  For each: every shortcut on vs
+    `sst_mode = 0` (the literal algorithm on the FM index) by device-side digests of all four result arrays over ALL reads, and a strided sample
+    of 100,000 reads (every 20th) bit for bit against the oracle.  Reference: bwt_smem1a's sweep whose equal-size merging must survive
+    (FM_index/bwt.c:325-345) and the re-seeding rule (mapping/bwamem.c:241-249), which these reads exercise on every call."""
+    import torch
+    import compseed_amd as ca
+    import synth
+    n = 2_000_000
+    G = synth.make_genome(500_000_000, seed=20261004, device="cuda", **synth.PROFILES["repeat50"]["genome"])
+    ix = ca.Index.build(G.cpu().numpy(), 0)
+    eng = ca.Engine(ix, 0)
+    bw, sa = ix.arrays()
+    v = ix.view
+    o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
+    ids = np.arange(0, n, 20, dtype=np.uint64)
+    sel = (ids[:, None].astype(np.int64) * 150 + np.arange(150)[None, :]).reshape(-1)
+    ho = (np.arange(ids.size + 1, dtype=np.uint64) * np.uint64(150))
+    wide = 0
+    for k, rkw in enumerate((dict(p_sub=0.005), dict(p_sub=0.01, p_indel=0.001), dict(p_sub=0.02, p_indel=0.001))):
+        bases, off = synth.make_reads(G, n, 150, seed=900 + k, sort=True, **rkw)
+        hb = bases[torch.from_numpy(sel).to(bases.device)].cpu().numpy()
+        torch.cuda.synchronize()
+        eng.reset_stats()
+        eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params())
+        d_on = eng.result_digest()
+        st = eng.stats()
+        assert st["reseed_text_calls"] > 0 and st["r3_text_seeds"] > 0 and st["sweep_text_calls"] > 0 and st["bwt_calls"] < st["bwt_queries"]
+        got = eng.gather_reads(ids)
+        want = o.seed_batch(hb, ho, _oracle.make_params(), mode=1, threads=16)
+        assert np.array_equal(got.mem_off, want["mem_off"]) and np.array_equal(got.mems, want["mems"]), rkw
+        assert np.array_equal(got.seed_off, want["seed_off"]) and np.array_equal(got.seeds, want["seeds"]), rkw
+        wide += int((np.diff(want["mem_off"].astype(np.int64)) > 64).sum())               # reads with more mems than the first-pass arena holds per read
+        eng.reset_stats()
+        eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(sst_mode=0))
+        st0 = eng.stats()
+        assert st0["bwt_calls"] == st0["bwt_queries"] and st0["reseed_text_calls"] == 0
+        assert eng.result_digest() == d_on, rkw                                    # all 2 M reads, all four arrays
+        del bases, off
+    assert wide > 0                                                                # ... occurred: the overflow records and the wave-per-read sort were exercised
+    o.close(); eng.close(); ix.close()
+
+
 def test_full_baseline_size_properties():
     """BASELINE configs[1] shape: hg19-size index (rows > 2^32: the 64-bit suffix-array / inverse-SA instantiation), 10 M x 150 bp
     reads.  For the default parameters and for configs[4]'s aggressive re-seeding (-r 1.0 -y 20):
       * every shortcut on vs `sst_mode = 0` (the literal algorithm on the FM index): device-side digests of all four result
         arrays over all 10 M reads must be equal -- no 6 GB download;
-      * a strided sample of 20,000 reads (every 500th, so the whole genome incl. its repeats is covered) bit-exact vs the oracle;
+      * a strided sample of 100,000 reads (every 100th, so the whole genome incl. its repeats is covered) bit-exact vs the oracle;
       * cheap size-independent checks streamed through the host: counts, sortedness, filters; two runs give the same digest."""
     import torch
     import compseed_amd as ca
@@ -238,7 +283,7 @@ def test_full_baseline_size_properties():
     bw, sa = ix.arrays()
     v = ix.view
     o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
-    ids = np.arange(0, n, n // 20000, dtype=np.uint64)[:20000]
+    ids = np.arange(0, n, n // 100000, dtype=np.uint64)[:100000]               # every 100th read: 100,000 reads against the oracle
     sel = (ids[:, None].astype(np.int64) * 150 + np.arange(150)[None, :]).reshape(-1)
     hb = bases[torch.from_numpy(sel).to(bases.device)].cpu().numpy()
     ho = (np.arange(ids.size + 1, dtype=np.uint64) * np.uint64(150))
