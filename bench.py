@@ -479,7 +479,7 @@ def main():
             pm = rp["mems"][sel_m]
             ok_p = np.array_equal(ca.unpack_mems16(pm) if rp["mem_format"] == 1 else pm, want["mems"])
             if not args.no_sal:
-                ok_p = ok_p and np.array_equal(rp["seed_rbeg"][sel_s], want["seeds"]["rbeg"])
+                ok_p = ok_p and np.array_equal(ca.packed_rbeg(rp, sel_s), want["seeds"]["rbeg"])
             # a stream of batches, two in flight (cs_engine_submit / cs_engine_collect_packed): upload of batch n+1, seeding of batch n
             # and download of batch n-1 overlap -- how the reference drives this stage (kt_pipeline, main.cpp:438)
             nstream = 5
@@ -499,7 +499,7 @@ def main():
             pm = rs_["mems"][sel_m]
             ok_s = np.array_equal(ca.unpack_mems16(pm) if rs_["mem_format"] == 1 else pm, want["mems"])
             if not args.no_sal:
-                ok_s = ok_s and np.array_equal(rs_["seed_rbeg"][sel_s], want["seeds"]["rbeg"])
+                ok_s = ok_s and np.array_equal(ca.packed_rbeg(rs_, sel_s), want["seeds"]["rbeg"])
             ok_p = ok_p and ok_s
             hb_page = np.array(hb_pin)                        # the same from pageable memory (staged by the upload thread)
             dt_g, _ = timed(lambda: eng.seed_batch(hb_page, ho_all, par, copy=False))
@@ -508,7 +508,7 @@ def main():
                 "packed_reads_per_s": args.reads / dt_p, "packed_ms_per_step": 1e3 * dt_p,
                 "pipelined_packed_reads_per_s": args.reads / dt_s, "pipelined_packed_ms_per_batch": 1e3 * dt_s,
                 "pageable_input_reads_per_s": args.reads / dt_g,
-                "bit_exact_vs_oracle": bool(ok_x and ok_p), "packed_bytes_per_read": (rp["mems"].nbytes + (rp["seed_rbeg"].nbytes if not args.no_sal else 0) + 16 * args.reads) / args.reads,
+                "bit_exact_vs_oracle": bool(ok_x and ok_p), "packed_bytes_per_read": (rp["mems"].nbytes + (rp["seed_rbeg_lo"].nbytes + rp["seed_rbeg_hi"].nbytes if not args.no_sal else 0) + 16 * args.reads) / args.reads,
                 "sub_batch_reads": int(eng.options.pipeline_reads), "expand_threads": int(eng.options.expand_threads),
                 "note": "rank 0, whole call: reads_per_s = cs_engine_seed_batch (reads from pinned host memory in, cs_intv_t / cs_seed_t arrays in host memory "
                         "out: upload, seeding, download and the host-side expansion of the packed results overlapped over sub-batches); packed_reads_per_s = "

@@ -17,7 +17,8 @@ SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", 
            "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
-           "cs_device_download", "cs_device_sync"]
+           "cs_device_download", "cs_device_sync", "cs_packed_seed_rbeg", "cs_engine_check_index",
+           "cs_ext_params_default", "cs_extender_create", "cs_extender_destroy", "cs_extend_batch", "cs_extend_batch_device", "cs_extender_stats"]
 
 
 class CSError(RuntimeError):
@@ -91,7 +92,8 @@ CHAIN_DT = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n_seeds", "<i4"), ("frac_
 
 class CPacked(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("n_mems", C.c_uint64), ("n_seeds", C.c_uint64), ("mem_format", C.c_int32), ("max_occ", C.c_int32),
-                ("mem_off", C.c_void_p), ("mems", C.c_void_p), ("seed_off", C.c_void_p), ("seed_rbeg", C.c_void_p)]
+                ("mem_off", C.c_void_p), ("mems", C.c_void_p), ("seed_off", C.c_void_p), ("seed_format", C.c_int32), ("reserved", C.c_int32),
+                ("seed_rbeg_lo", C.c_void_p), ("seed_rbeg_hi", C.c_void_p)]
 
 
 MEM16_DT = np.dtype([("w0", "<u8"), ("w1", "<u8")])   # cs_mem16_t
@@ -126,8 +128,29 @@ class ExtParams(C.Structure):
         self.o_del, self.e_del, self.o_ins, self.e_ins, self.zdrop, self.end_bonus = o_del, e_del, o_ins, e_ins, zdrop, end_bonus
 
 
+class IndexCheck(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rows_checked", "order_violations", "isa_violations", "bwt_violations", "sampled_sa_violations", "undecided_rows",
+                                          "text_violations")] + [("text_checked", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ExtStats(C.Structure):
     _fields_ = [("pairs", C.c_uint64), ("cells", C.c_uint64), ("rows", C.c_uint64), ("launches", C.c_uint64), ("kernel_ms", C.c_double)]
+
+
+class PackedResult(dict):
+    """cs_packed_result_t as a dict of zero-copy views; "seed_rbeg" is the 40-bit positions expanded to int64 on first use
+    (cs_packed_seed_rbeg for every seed); packed_rbeg(p, sel) expands a selection only"""
+
+    def __missing__(self, key):
+        if key == "seed_rbeg":
+            v = None if self["seed_rbeg_lo"] is None else packed_rbeg(self, slice(None))
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+
+def packed_rbeg(p, sel):
+    return p["seed_rbeg_lo"][sel].astype(np.int64) | (p["seed_rbeg_hi"][sel].astype(np.int64) << 32)
 
 
 class Stats(C.Structure):
@@ -254,6 +277,7 @@ def load_library():
     L.cs_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
     L.cs_device_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.cs_device_sync.argtypes = [vp]
+    L.cs_engine_check_index.argtypes = [vp, vp, C.c_uint64, C.POINTER(IndexCheck)]
     L.cs_ext_params_default.argtypes = [C.POINTER(ExtParams)]
     L.cs_ext_params_default.restype = None
     L.cs_extender_create.argtypes = [C.c_int, C.POINTER(ExtParams), C.POINTER(vp)]
@@ -548,11 +572,12 @@ class Engine:
     def _packed(res):
         n = int(res.n_reads)
         sal = bool(res.seed_off)
-        return dict(n_reads=n, n_mems=int(res.n_mems), n_seeds=int(res.n_seeds), mem_format=int(res.mem_format), max_occ=int(res.max_occ),
-                    mem_off=_view(res.mem_off, "<u8", n + 1, False),
-                    mems=_view(res.mems, MEM16_DT if res.mem_format == 1 else INTV_DT, int(res.n_mems), False),
-                    seed_off=_view(res.seed_off, "<u8", n + 1, False) if sal else None,
-                    seed_rbeg=_view(res.seed_rbeg, "<i8", int(res.n_seeds), False) if sal else None)
+        return PackedResult(n_reads=n, n_mems=int(res.n_mems), n_seeds=int(res.n_seeds), mem_format=int(res.mem_format), max_occ=int(res.max_occ),
+                            mem_off=_view(res.mem_off, "<u8", n + 1, False),
+                            mems=_view(res.mems, MEM16_DT if res.mem_format == 1 else INTV_DT, int(res.n_mems), False),
+                            seed_off=_view(res.seed_off, "<u8", n + 1, False) if sal else None, seed_format=int(res.seed_format),
+                            seed_rbeg_lo=_view(res.seed_rbeg_lo, "<u4", int(res.n_seeds), False) if sal else None,
+                            seed_rbeg_hi=_view(res.seed_rbeg_hi, "u1", int(res.n_seeds), False) if sal else None)
 
     def seed_batch_device(self, d_bases, d_offsets, n_reads, n_bases, params=None):
         """Device pointers (ints) in, device pointers out (cs_engine_seed_batch_device): no PCIe traffic in the call."""
@@ -591,6 +616,12 @@ class Engine:
                 tot += b
         out["bytes"] = tot
         return out
+
+    def check_index(self, d_fwd_nt4=None, l_pac=0):
+        """cs_engine_check_index: violation counts of the resident index against the text (and, when given, the caller's genome on the device)"""
+        c = IndexCheck()
+        _check(self._L.cs_engine_check_index(self._h, int(d_fwd_nt4) if d_fwd_nt4 else None, int(l_pac), C.byref(c)))
+        return {n: int(getattr(c, n)) for n, _ in IndexCheck._fields_ if n != "reserved"}
 
     def stats(self):
         st = Stats()

@@ -126,7 +126,7 @@ int main(int argc, char **argv)
 						cs_intv_t v; cs_unpack_mem(&R, m, &v);
 						const uint32_t cnt = cs_mem_seed_count(&v, R.max_occ);
 						for (uint32_t k = 0; k < cnt; ++k)
-							fprintf(fo, "S\t%lu\t%d\t%d\t%ld\n", (unsigned long)id, (int)(v.info >> 32), (int)((uint32_t)v.info - (uint32_t)(v.info >> 32)), (long)R.seed_rbeg[sd + k]);
+							fprintf(fo, "S\t%lu\t%d\t%d\t%ld\n", (unsigned long)id, (int)(v.info >> 32), (int)((uint32_t)v.info - (uint32_t)(v.info >> 32)), (long)cs_packed_seed_rbeg(&R, sd + k));
 						sd += cnt;
 					}
 			}

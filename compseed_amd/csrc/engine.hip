@@ -148,8 +148,8 @@ struct cs_engine {
 	size_t lep_arena_bytes = (size_t)32 << 30;
 	// host variants (seed_host_pipelined): copy streams, two input slots, two pack slots, pinned packed results, expanded results
 	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[2] = {nullptr, nullptr};
-	DevBuf<uint8_t> hp_in[2], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[2], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<int64_t> hp_pk_rbeg[2];
-	PinBuf<uint64_t> hp_moff[2], hp_soff[2]; PinBuf<uint8_t> hp_mems[2]; PinBuf<int64_t> hp_rbeg[2]; // two pinned result slots
+	DevBuf<uint8_t> hp_in[2], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[2], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<uint32_t> hp_pk_rlo[2]; DevBuf<uint8_t> hp_pk_rhi[2]; // seeds: low words and fifth bytes of rbeg
+	PinBuf<uint64_t> hp_moff[2], hp_soff[2]; PinBuf<uint8_t> hp_mems[2]; PinBuf<uint32_t> hp_rlo[2]; PinBuf<uint8_t> hp_rhi[2]; // two pinned result slots
 	struct HostPipe *hp = nullptr;
 	HostBuf<cs_intv_t> x_mems; HostBuf<cs_seed_t> x_seeds;
 	cs_stats_t st{};
@@ -452,8 +452,8 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_evc.release(); e->d_sel.release(); e->d_sel_moff.release(); e->d_sel_soff.release(); e->d_sel_mems.release(); e->d_sel_seeds.release();
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
-	for (int k = 0; k < 2; ++k) { e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rbeg[k].release(); }
-	for (int k = 0; k < 2; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rbeg[k].release(); }
+	for (int k = 0; k < 2; ++k) { e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
+	for (int k = 0; k < 2; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
 	e->x_mems.release(); e->x_seeds.release();
 	for (auto &ev : e->hp_ev_done) if (ev) (void)hipEventDestroy(ev);
 	for (auto &ev : e->hp_ev_pk) if (ev) (void)hipEventDestroy(ev);
@@ -1110,9 +1110,11 @@ __global__ void pack_mems16_kernel(const OutMem *m, uint64_t n, uint4 *out)
 		out[i] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
 	}
 }
-__global__ void pack_rbeg_kernel(const OutSeed *sd, uint64_t n, int64_t *out)
+// a seed travels as its rbeg only, in 40 bits: positions are below 2^37 (checked at engine creation), so the low word and the fifth byte go
+// into two planes (coalesced stores, aligned loads for the consumer: cs_packed_seed_rbeg) -- 5 instead of 8 bytes of PCIe traffic per seed
+__global__ void pack_rbeg_kernel(const OutSeed *sd, uint64_t n, uint32_t *lo, uint8_t *hi)
 {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = sd[i].rbeg;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { const uint64_t v = (uint64_t)sd[i].rbeg; lo[i] = (uint32_t)v; hi[i] = (uint8_t)(v >> 32); }
 }
 __global__ void shift_words_kernel(const uint64_t *in, uint64_t n, uint64_t add, uint64_t *out)
 {
@@ -1152,7 +1154,7 @@ void expand_range(const cs_packed_result_t &P, cs_intv_t *mems, cs_seed_t *seeds
 			if (P.seed_off) {
 				const int32_t qb = (int32_t)(v.info >> 32), ln = (int32_t)(uint32_t)v.info - qb;
 				const uint32_t c = cs_mem_seed_count(&v, P.max_occ);
-				for (uint32_t j = 0; j < c; ++j) { cs_seed_t x = {P.seed_rbeg[sd + j], qb, ln}; seeds[sd + j] = x; }
+				for (uint32_t j = 0; j < c; ++j) { cs_seed_t x = {cs_packed_seed_rbeg(&P, sd + j), qb, ln}; seeds[sd + j] = x; }
 				sd += c;
 			}
 		}
@@ -1260,7 +1262,7 @@ static void pipe_expand_thread(cs_engine *e)
 		if (ok) {
 			cs_packed_result_t Q; memset(&Q, 0, sizeof Q);
 			Q.n_reads = b.n_reads; Q.mem_format = b.pk16 ? CS_MEM_PACKED16 : CS_MEM_FULL32; Q.max_occ = b.max_occ;
-			Q.mem_off = e->hp_moff[rs].p; Q.mems = e->hp_mems[rs].p; Q.seed_off = b.sal ? e->hp_soff[rs].p : nullptr; Q.seed_rbeg = b.sal ? e->hp_rbeg[rs].p : nullptr;
+			Q.mem_off = e->hp_moff[rs].p; Q.mems = e->hp_mems[rs].p; Q.seed_off = b.sal ? e->hp_soff[rs].p : nullptr; Q.seed_format = CS_SEED_RBEG40; Q.seed_rbeg_lo = b.sal ? e->hp_rlo[rs].p : nullptr; Q.seed_rbeg_hi = b.sal ? e->hp_rhi[rs].p : nullptr;
 			expand_parallel(Q, e->x_mems.p, e->x_seeds.p, x.r0, x.r0 + x.n, e->opt.expand_threads);
 		}
 		std::lock_guard<std::mutex> lk(hp.mu);
@@ -1308,15 +1310,16 @@ static void pipe_seed_thread(cs_engine *e)
 			if (j.part == 0 && (e->hp_moff[rs].reserve((size_t)j.n_reads + 1) != CS_OK || (sal && e->hp_soff[rs].reserve((size_t)j.n_reads + 1) != CS_OK))) { rc = CS_ENOMEM; err = g_err; }
 			// pinned room for the whole batch: estimated from its first part, grown (keeping what has arrived) if that was too little
 			const size_t need_m = (size_t)(mem_base + nm), need_s = (size_t)(seed_base + ns);
-			if (need_m * msz > e->hp_mems[rs].cap || (sal && need_s > e->hp_rbeg[rs].cap)) {
+			if (need_m * msz > e->hp_mems[rs].cap || (sal && need_s > e->hp_rlo[rs].cap)) {
 				hipf(hipStreamSynchronize(e->s_down), "draining downloads before growing the result buffers");
 				{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || (hp.q_x.empty() && !hp.x_busy); }); if (hp.quit) return; } // the expander reads these buffers
 				const double scale = (double)j.n_reads / (double)(j.r0 + j.n) * 1.08;
 				if (rc == CS_OK && e->hp_mems[rs].reserve((size_t)((double)need_m * scale) * msz + 4096, true, (size_t)mem_base * msz) != CS_OK) { rc = CS_ENOMEM; err = g_err; }
-				if (rc == CS_OK && sal && e->hp_rbeg[rs].reserve((size_t)((double)need_s * scale) + 512, true, (size_t)seed_base) != CS_OK) { rc = CS_ENOMEM; err = g_err; }
+				if (rc == CS_OK && sal && (e->hp_rlo[rs].reserve((size_t)((double)need_s * scale) + 512, true, (size_t)seed_base) != CS_OK ||
+				                            e->hp_rhi[rs].reserve((size_t)((double)need_s * scale) + 512, true, (size_t)seed_base) != CS_OK)) { rc = CS_ENOMEM; err = g_err; }
 			}
 		}
-		if (rc == CS_OK && (e->hp_pk_mems[ps].reserve((size_t)nm * msz + 64) != CS_OK || (sal && e->hp_pk_rbeg[ps].reserve((size_t)ns + 8) != CS_OK))) { rc = CS_ENOMEM; err = g_err; }
+		if (rc == CS_OK && (e->hp_pk_mems[ps].reserve((size_t)nm * msz + 64) != CS_OK || (sal && (e->hp_pk_rlo[ps].reserve((size_t)ns + 8) != CS_OK || e->hp_pk_rhi[ps].reserve((size_t)ns + 8) != CS_OK)))) { rc = CS_ENOMEM; err = g_err; }
 		if (rc == CS_OK) {
 			hipStream_t s = e->stream;
 			const unsigned g = (unsigned)e->n_cu * 8;
@@ -1327,7 +1330,7 @@ static void pipe_seed_thread(cs_engine *e)
 			}
 			if (sal) {
 				hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_seed_off.p, (uint64_t)j.n + 1, seed_base, e->hp_pk_soff[ps].p);
-				if (ns) hipLaunchKernelGGL(pack_rbeg_kernel, dim3(g), dim3(256), 0, s, (const OutSeed *)e->d_seeds.p, ns, e->hp_pk_rbeg[ps].p);
+				if (ns) hipLaunchKernelGGL(pack_rbeg_kernel, dim3(g), dim3(256), 0, s, (const OutSeed *)e->d_seeds.p, ns, e->hp_pk_rlo[ps].p, e->hp_pk_rhi[ps].p);
 			}
 			hipf(hipGetLastError(), "pack kernels");
 			hipf(hipEventRecord(e->hp_ev_pk[ps], s), "event");
@@ -1336,7 +1339,8 @@ static void pipe_seed_thread(cs_engine *e)
 			if (nm) hipf(hipMemcpyAsync(e->hp_mems[rs].p + (size_t)mem_base * msz, e->hp_pk_mems[ps].p, (size_t)nm * msz, hipMemcpyDeviceToHost, e->s_down), "download");
 			if (sal) {
 				hipf(hipMemcpyAsync(e->hp_soff[rs].p + j.r0, e->hp_pk_soff[ps].p, ((size_t)j.n + 1) * 8, hipMemcpyDeviceToHost, e->s_down), "download");
-				if (ns) hipf(hipMemcpyAsync(e->hp_rbeg[rs].p + seed_base, e->hp_pk_rbeg[ps].p, (size_t)ns * 8, hipMemcpyDeviceToHost, e->s_down), "download");
+				if (ns) hipf(hipMemcpyAsync(e->hp_rlo[rs].p + seed_base, e->hp_pk_rlo[ps].p, (size_t)ns * 4, hipMemcpyDeviceToHost, e->s_down), "download");
+				if (ns) hipf(hipMemcpyAsync(e->hp_rhi[rs].p + seed_base, e->hp_pk_rhi[ps].p, (size_t)ns, hipMemcpyDeviceToHost, e->s_down), "download");
 			}
 			hipf(hipEventRecord(e->hp_ev_dn[k % 4], e->s_down), "event");
 			if (j.part + 1 == j.n_parts) hipf(hipEventRecord(e->hp_ev_done[rs], e->s_down), "event");
@@ -1462,7 +1466,8 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 	out->n_reads = b.n_reads; out->n_mems = b.mem_base; out->n_seeds = b.seed_base; out->max_occ = b.max_occ;
 	out->mem_format = b.pk16 ? CS_MEM_PACKED16 : CS_MEM_FULL32;
 	out->mem_off = e->hp_moff[rs].p; out->mems = e->hp_mems[rs].p;
-	out->seed_off = b.sal ? e->hp_soff[rs].p : nullptr; out->seed_rbeg = b.sal ? e->hp_rbeg[rs].p : nullptr;
+	out->seed_off = b.sal ? e->hp_soff[rs].p : nullptr; out->seed_format = CS_SEED_RBEG40;
+	out->seed_rbeg_lo = b.sal ? e->hp_rlo[rs].p : nullptr; out->seed_rbeg_hi = b.sal ? e->hp_rhi[rs].p : nullptr;
 	{ // cs_engine_result_digest / gather_reads work on the device-side result, which is the whole batch only if it was not cut
 		std::lock_guard<std::mutex> lk(hp.mu); // (a submit on another thread invalidates it under the same lock)
 		e->last.valid = b.parts_total == 1 && !pipe_busy(e); e->last.n_reads = b.n_reads; e->last.n_mems = b.mem_base; e->last.n_seeds = b.seed_base; e->last.want_sal = b.sal;
@@ -1596,6 +1601,77 @@ extern "C" int cs_engine_gather_reads(cs_engine_t *e, int64_t n_sel, const uint6
 	out->n_reads = n_sel; out->n_mems = nm; out->n_seeds = ns;
 	out->mem_off = e->h_mem_off.p; out->mems = (const cs_intv_t *)e->h_mems.p;
 	out->seed_off = sal ? e->h_seed_off.p : nullptr; out->seeds = sal ? (const cs_seed_t *)e->h_seeds.p : nullptr;
+	return CS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ index validation at the size it is used
+// The index a 3.1 Gbp engine runs on is built on the GPU in the same process (index_build.hip), and the arrays the shortcuts read are derived
+// from it at engine creation; the byte-for-byte comparisons with bwaidx stop at 64 Mbp.  This check is independent of how any of it was
+// made: (1) the recovered 2-bit text equals the caller's genome and its reverse complement; (2) every pair of neighbouring rows of the
+// full suffix array is in suffix order, decided by comparing the TEXT (end of text smallest, as the sentinel); (3) ISA[SA[r]] = r, so
+// SA is a permutation; (4) the BWT character of row r is T[SA[r] - 1] and the row of suffix 0 is `primary`; (5) the sampled suffix
+// array of the file equals the full one at the sampled rows.  (1)-(3) make SA THE suffix array of the given text, (4)-(5) tie the
+// reference's two files to it (FM_index/bwt.c:62-96, index_main.c:152-174).
+__global__ void check_text_kernel(const DevIndex ix, const uint8_t *fwd, uint64_t l_pac, unsigned long long *bad)
+{
+	unsigned long long c = 0;
+	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < l_pac; p += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t q = 2 * l_pac - 1 - p;                       // the position of base p on the reverse-complement strand
+		const uint32_t f = fwd[p] & 3u;
+		const uint32_t a = (ix.text2[p >> 4] >> ((p & 15) << 1)) & 3u, b = (ix.text2[q >> 4] >> ((q & 15) << 1)) & 3u;
+		c += (a != f) + (b != 3u - f);
+	}
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+	if ((threadIdx.x & 63) == 0 && c) atomicAdd(bad, c);
+}
+__global__ void check_rows_kernel(const DevIndex ix, uint32_t cap, unsigned long long *out /* [0] order [1] isa [2] bwt [3] sampled SA [4] undecided (LCP beyond cap) */)
+{
+	unsigned long long v[5] = {0, 0, 0, 0, 0};
+	const uint32_t *t2 = ix.text2;
+	auto base = [&](uint64_t p) { return (t2[p >> 4] >> ((p & 15) << 1)) & 3u; };
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; r <= ix.seq_len; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t a = r == 1 ? ix.seq_len : sa_direct(ix, r - 1), b = sa_direct(ix, r);
+		if (b >= ix.seq_len || a > ix.seq_len) { ++v[0]; continue; }
+		const uint32_t l = text_lcp(ix, a, b, cap);
+		if (l >= cap) ++v[4];
+		else if (!(a + l == ix.seq_len || (b + l < ix.seq_len && base(a + l) < base(b + l)))) ++v[0];
+		if (isa_direct(ix, b) != r) ++v[1];
+		if (b == 0) { if (r != ix.primary) ++v[2]; }
+		else {
+			if (r == ix.primary) ++v[2];
+			else {
+				const uint64_t row = r - (r > ix.primary);
+				const Block k = load_block(ix, row >> OCC_SHIFT);
+				const uint32_t p = (uint32_t)row & OCC_MASK, w = p >> 5, bit = p & 31;
+				const uint32_t lo = w == 0 ? k.pl.x : k.pl.y, hi = w == 0 ? k.pl.z : k.pl.w;
+				if ((((lo >> bit) & 1u) | (((hi >> bit) & 1u) << 1)) != base(b - 1)) ++v[2];
+			}
+		}
+		if ((r & ix.sa_mask) == 0 && ix.sa[r >> ix.sa_shift] != b) ++v[3];
+	}
+	for (int i = 0; i < 5; ++i) {
+		unsigned long long c = v[i];
+		for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+		if ((threadIdx.x & 63) == 0 && c) atomicAdd(out + i, c);
+	}
+}
+extern "C" int cs_engine_check_index(cs_engine_t *e, const uint8_t *d_fwd_nt4, uint64_t l_pac, cs_index_check_t *out)
+{
+	if (!e || !out) return fail(CS_EINVAL, "cs_engine_check_index: null argument");
+	if (pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_check_index: submitted batches are in flight, collect them first");
+	if (!e->ix.text2 || !(e->ix.fsa32 || e->ix.fsa64)) return fail(CS_EINVAL, "cs_engine_check_index: needs the full suffix array and the text arrays (engine options full_sa, text_mode)");
+	if (d_fwd_nt4 && 2 * l_pac != e->ix.seq_len) return fail(CS_EINVAL, "cs_engine_check_index: l_pac is not half of the index length");
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t s = e->stream;
+	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 8 * sizeof(unsigned long long), s));
+	const unsigned grid = (unsigned)e->n_cu * 16;
+	if (d_fwd_nt4) hipLaunchKernelGGL(check_text_kernel, dim3(grid), dim3(256), 0, s, e->ix, d_fwd_nt4, l_pac, e->d_ctr.p + 5);
+	hipLaunchKernelGGL(check_rows_kernel, dim3(grid), dim3(256), 0, s, e->ix, 1u << 20, e->d_ctr.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_ctr.p, e->d_ctr.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	out->rows_checked = e->ix.seq_len; out->order_violations = e->h_ctr.p[0]; out->isa_violations = e->h_ctr.p[1]; out->bwt_violations = e->h_ctr.p[2];
+	out->sampled_sa_violations = e->h_ctr.p[3]; out->undecided_rows = e->h_ctr.p[4]; out->text_violations = e->h_ctr.p[5]; out->text_checked = d_fwd_nt4 ? 1 : 0;
 	return CS_OK;
 }
 

@@ -76,7 +76,7 @@ struct ExtArgs {
 	unsigned long long *stat;          // [0] DP cells computed, [1] rows
 };
 
-// the scoring rule (oracle/cs_bsw_oracle.c states both): the reference's vectorised code compares codes (mapping/bandedSWA.cpp:286-290),
+// the two scoring rules of the reference: its vectorised code compares codes (mapping/bandedSWA.cpp:286-290),
 // its scalar code -- used for pairs of 32768 bases or more, comp_seed.cpp:1569-1577 -- indexes the matrix (ksw.c:392-395)
 __device__ __forceinline__ int pair_score(const ExtParams &P, const int8_t *mat, bool vec_rule, int t, int q)
 {

@@ -196,13 +196,13 @@ int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t
 /* ---- packed results: what actually crosses PCIe.  A 10 M-read batch produces ~80 M mems and ~200 M seeds, 5.9 GB as cs_intv_t /
  *      cs_seed_t -- more transfer time than seeding time -- but half of those bytes are implied: a seed's qbeg and len are its
  *      mem's, a mem's seeds are its first min(x2, max_occ) slots (comp_seed.cpp:2313-2325), and three 33-bit coordinates, a 32-bit
- *      size and two 15-bit query positions fit 16 bytes.  cs_engine_seed_batch_packed returns that form in pinned host memory;
+ *      size and two 15-bit query positions fit 16 bytes, a reference position 5.  cs_engine_seed_batch_packed returns that form in pinned host memory;
  *      a consumer that copies per read anyway (the reference does: aux.match[r] / aux.seed[r] are per-read vectors) unpacks on
  *      the fly in its own worker threads with the inline helpers below, and cs_engine_seed_batch is this call followed by a
  *      multi-threaded expansion into cs_intv_t / cs_seed_t arrays.  Both split the batch into sub-batches and overlap the upload
  *      of the next, the seeding of the current and the download (and expansion) of the previous one.
  *      mem_format CS_MEM_PACKED16 needs an index shorter than 2^33 symbols and reads shorter than 2^15 bases (hg19 / T2T, short
- *      reads); anything else comes back as CS_MEM_FULL32 (plain cs_intv_t), seeds as rbeg either way. */
+ *      reads); anything else comes back as CS_MEM_FULL32 (plain cs_intv_t); seeds as their rbeg in 40 bits either way. */
 #define CS_MEM_FULL32   0
 #define CS_MEM_PACKED16 1
 typedef struct { uint64_t w0, w1; } cs_mem16_t;
@@ -215,8 +215,13 @@ typedef struct {
 	const uint64_t *mem_off;     /* n_reads + 1 */
 	const void     *mems;        /* cs_mem16_t[n_mems] or cs_intv_t[n_mems] */
 	const uint64_t *seed_off;    /* n_reads + 1, NULL when want_sal == 0 */
-	const int64_t  *seed_rbeg;   /* n_seeds, in mem-then-slot order */
+	int32_t   seed_format;       /* CS_SEED_RBEG40: a seed's rbeg as 40 bits in two planes (reference positions are below 2^37) */
+	int32_t   reserved;
+	const uint32_t *seed_rbeg_lo; /* n_seeds low words, in mem-then-slot order */
+	const uint8_t  *seed_rbeg_hi; /* n_seeds fifth bytes: rbeg = lo | (int64_t)hi << 32 (cs_packed_seed_rbeg) */
 } cs_packed_result_t;
+#define CS_SEED_RBEG40 1
+static inline int64_t cs_packed_seed_rbeg(const cs_packed_result_t *r, uint64_t i) { return (int64_t)((uint64_t)r->seed_rbeg_lo[i] | (uint64_t)r->seed_rbeg_hi[i] << 32); }
 int  cs_engine_seed_batch_packed(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                                  const uint8_t *bases, const uint64_t *offsets, cs_packed_result_t *out);
 /* The same as a two-deep pipeline across batches, the counterpart of the reference's kt_pipeline (main.cpp:438: read chunk n+1 while
@@ -329,6 +334,17 @@ typedef struct {
 	                            written again */
 } cs_traffic_t;
 int  cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out);
+
+/* ---- validation of the resident index at the size it is used (the byte-for-byte comparisons with bwaidx's files stop at 64 Mbp): counts
+ *      violations of (1) recovered text == `d_fwd_nt4` (device memory, codes 0..3, l_pac bases; NULL skips this) and its reverse complement,
+ *      (2) suffix order of every neighbouring pair of rows of the full suffix array, decided on the text, (3) ISA[SA[r]] == r, (4) BWT character
+ *      of row r == T[SA[r] - 1] and the row of suffix 0 == primary, (5) sampled SA == full SA at the sampled rows (bwt_cal_sa, bwt.c:62-96).
+ *      All zero <=> the .bwt / .sa pair is the FM index of that text.  undecided_rows: pairs that share more than 2^20 bases. */
+typedef struct {
+	uint64_t rows_checked, order_violations, isa_violations, bwt_violations, sampled_sa_violations, undecided_rows, text_violations;
+	int32_t  text_checked, reserved;
+} cs_index_check_t;
+int  cs_engine_check_index(cs_engine_t *e, const uint8_t *d_fwd_nt4, uint64_t l_pac, cs_index_check_t *out);
 
 int  cs_engine_stats(const cs_engine_t *e, cs_stats_t *st);
 void cs_engine_reset_stats(cs_engine_t *e);

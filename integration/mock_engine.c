@@ -16,7 +16,7 @@ struct cs_engine {
 	cso_index_t ix;
 	struct { cs_params_t par; int64_t n; const uint8_t *bases; const uint64_t *off; } q[2];
 	uint64_t n_sub, n_col;
-	struct { uint64_t *mem_off, *seed_off; cs_mem16_t *mems; int64_t *rbeg; } res[2];
+	struct { uint64_t *mem_off, *seed_off; cs_mem16_t *mems; uint32_t *rlo; uint8_t *rhi; } res[2];
 	cs_stats_t st;
 };
 static const char *g_err = "";
@@ -40,7 +40,7 @@ int cs_engine_create(const cs_index_view_t *v, int device, cs_engine_t **out)
 void cs_engine_destroy(cs_engine_t *e)
 {
 	if (!e) return;
-	for (int k = 0; k < 2; ++k) { free(e->res[k].mem_off); free(e->res[k].seed_off); free(e->res[k].mems); free(e->res[k].rbeg); }
+	for (int k = 0; k < 2; ++k) { free(e->res[k].mem_off); free(e->res[k].seed_off); free(e->res[k].mems); free(e->res[k].rlo); free(e->res[k].rhi); }
 	free(e);
 }
 int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st) { *st = e->st; return CS_OK; }
@@ -58,20 +58,20 @@ int cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out)
 	cso_params_t op = {e->q[k].par.min_seed_len, e->q[k].par.split_factor, e->q[k].par.split_width, e->q[k].par.max_occ, e->q[k].par.max_mem_intv};
 	uint64_t *mo = NULL, *so = NULL; cso_intv_t *mm = NULL; cso_seed_t *ss = NULL; cso_stats_t st;
 	if (cso_seed_batch(&e->ix, &op, e->q[k].n, e->q[k].bases, e->q[k].off, 1, 512, 1, 4, &mo, &mm, &so, &ss, &st)) { g_err = "oracle failed"; return CS_EDEVICE; }
-	free(e->res[k].mem_off); free(e->res[k].seed_off); free(e->res[k].mems); free(e->res[k].rbeg);
+	free(e->res[k].mem_off); free(e->res[k].seed_off); free(e->res[k].mems); free(e->res[k].rlo); free(e->res[k].rhi);
 	e->res[k].mem_off = mo; e->res[k].seed_off = so;
 	e->res[k].mems = (cs_mem16_t *)malloc((st.n_mems + 1) * sizeof(cs_mem16_t));
-	e->res[k].rbeg = (int64_t *)malloc((st.n_seeds + 1) * sizeof(int64_t));
+	e->res[k].rlo = (uint32_t *)malloc((st.n_seeds + 1) * sizeof(uint32_t)); e->res[k].rhi = (uint8_t *)malloc(st.n_seeds + 1);
 	for (uint64_t i = 0; i < st.n_mems; ++i) { /* the packing of include/compseed_amd.h (CS_MEM_PACKED16) */
 		uint64_t beg = mm[i].info >> 32, end = mm[i].info & 0xffffffffull;
 		e->res[k].mems[i].w0 = mm[i].x0 | (mm[i].x2 & 0x7fffffffull) << 33;
 		e->res[k].mems[i].w1 = mm[i].x1 | beg << 33 | end << 48 | (mm[i].x2 >> 31) << 63;
 	}
-	for (uint64_t i = 0; i < st.n_seeds; ++i) e->res[k].rbeg[i] = ss[i].rbeg;
+	for (uint64_t i = 0; i < st.n_seeds; ++i) { e->res[k].rlo[i] = (uint32_t)(uint64_t)ss[i].rbeg; e->res[k].rhi[i] = (uint8_t)((uint64_t)ss[i].rbeg >> 32); } /* CS_SEED_RBEG40 */
 	cso_free(mm); cso_free(ss);
 	memset(out, 0, sizeof *out);
 	out->n_reads = e->q[k].n; out->n_mems = st.n_mems; out->n_seeds = st.n_seeds; out->mem_format = CS_MEM_PACKED16; out->max_occ = e->q[k].par.max_occ;
-	out->mem_off = e->res[k].mem_off; out->mems = e->res[k].mems; out->seed_off = e->res[k].seed_off; out->seed_rbeg = e->res[k].rbeg;
+	out->mem_off = e->res[k].mem_off; out->mems = e->res[k].mems; out->seed_off = e->res[k].seed_off; out->seed_format = CS_SEED_RBEG40; out->seed_rbeg_lo = e->res[k].rlo; out->seed_rbeg_hi = e->res[k].rhi;
 	e->st.reads += (uint64_t)e->q[k].n; e->st.mems += st.n_mems; e->st.seeds += st.n_seeds; e->st.bwt_queries += st.bwt_queries; e->st.bwt_calls += st.bwt_calls;
 	return CS_OK;
 }

@@ -120,3 +120,41 @@ def digest_result(mem_off, mems, seed_off, seeds_rbeg, seeds_qbeg, seeds_len):
         return hashlib.md5(np.ascontiguousarray(a, dtype=dt).tobytes()).hexdigest()
     return {"mem_off": h(mem_off, "<u8"), "mems": h(mems, "<u8"), "seed_off": h(seed_off, "<u8"),
             "seed_rbeg": h(seeds_rbeg, "<i8"), "seed_qbeg": h(seeds_qbeg, "<i4"), "seed_len": h(seeds_len, "<i4")}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The index builder at a size where the reference's bwaidx takes its large-genome branch (bwt_bwtgen2, FM_index/index_main.c:277-283:
+# l_pac > 50,000,000 with both strands counted): a 64 Mbp genome in three contigs with planted repeats (a 300-bp family, exact
+# segmental copies, a tandem array, homopolymers) and two N runs.  numpy's PCG64 stream is the same wherever this numpy runs;
+# tests/golden/c2/config2.json holds the md5 digests of the five files the reference's bwaidx wrote for it (make_golden.py bigref).
+C2_LEN, C2_SEED = 64_000_000, 20261005
+
+
+def bigref_fasta(path):
+    """writes the FASTA (70 columns, three contigs); returns the number of bases"""
+    rng = np.random.default_rng(C2_SEED)
+    g = rng.integers(0, 4, C2_LEN, dtype=np.uint8)
+    elem = rng.integers(0, 4, 300, dtype=np.uint8)
+    for p in rng.integers(0, C2_LEN - 300, 4000):                       # interspersed family, 3 % divergence
+        cp = elem.copy(); m = rng.random(300) < 0.03; cp[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
+        g[p:p + 300] = cp
+    for _ in range(40):                                                  # exact 4-kb segmental copies: deep suffix comparisons
+        a, b = rng.integers(0, C2_LEN - 4000, 2)
+        g[b:b + 4000] = g[a:a + 4000]
+    unit = rng.integers(0, 4, 31, dtype=np.uint8)
+    g[20_000_000:20_000_000 + 31 * 2000] = np.tile(unit, 2000)           # tandem array
+    g[41_000_000:41_000_000 + 5000] = 0                                  # homopolymer
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    s = lut[g]
+    s[7_000_000:7_000_123] = ord("N"); s[50_500_000:50_500_040] = ord("N")
+    cuts = [0, 23_000_017, 47_999_990, C2_LEN]
+    with open(path, "wb") as f:
+        for k in range(3):
+            f.write((">ctg%d synthetic\n" % (k + 1)).encode())
+            c = s[cuts[k]:cuts[k + 1]]
+            full = (c.size // 70) * 70
+            rows = np.concatenate([c[:full].reshape(-1, 70), np.full((full // 70, 1), 10, np.uint8)], axis=1)
+            f.write(rows.tobytes())
+            if c.size > full:
+                f.write(c[full:].tobytes() + b"\n")
+    return C2_LEN

@@ -15,6 +15,7 @@ What is produced (all data, no reference source text):
   MANIFEST.json                      md5 of every file + the harness stderr summary per run
   bsw1/                              `make_golden.py bsw`: every banded-SW extension the reference performed on the read sets (inputs + 6 outputs),
                                      recorded from its own run, and known answers of its scalar ksw_extend2
+  c2/config2.json                    `make_golden.py bigref`: md5 of bwaidx's five files for a 64 Mbp genome (its bwt_bwtgen2 branch)
   alt1/                              `make_golden.py alt`: main100's chains with a <prefix>.alt file naming chr2 (is_alt of the chains)
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
                                      md5 digests of its complete output (`make_golden.py config1` regenerates only this)
@@ -293,6 +294,28 @@ def make_bsw():
     print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
 
 
+def make_bigref():
+    """c2/config2.json: md5 of the five index files the reference's bwaidx writes for the 64 Mbp genome of tests/_data.bigref_fasta() -- the
+    size at which it takes its large-genome branch (bwt_bwtgen2, index_main.c:277-283), which the 220-kbp and 4.6-Mbp fixtures do not reach."""
+    import tempfile, time
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _data
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "big.fa")
+        n = _data.bigref_fasta(fa)
+        t0 = time.time()
+        r = run([os.path.join(REFBIN, "bwaidx"), "-p", os.path.join(td, "big"), fa])
+        if r.returncode:
+            sys.exit(r.stderr)
+        assert "bwtgen2" in r.stderr or "BWTIncConstructFromPacked" in r.stderr or n * 2 > 50000000
+        out = {"recipe": "tests/_data.bigref_fasta()", "bases": n, "fasta_md5": md5(fa), "bwaidx_seconds": round(time.time() - t0, 1),
+               "index_md5": {ext: md5(os.path.join(td, "big." + ext)) for ext in ("bwt", "sa", "pac", "ann", "amb")},
+               "bwaidx_log_tail": r.stderr.strip().splitlines()[-6:]}
+    os.makedirs(os.path.join(HERE, "c2"), exist_ok=True)
+    json.dump(out, open(os.path.join(HERE, "c2", "config2.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
@@ -302,6 +325,8 @@ def main():
         return make_alt()
     if len(sys.argv) > 1 and sys.argv[1] == "bsw":
         return make_bsw()
+    if len(sys.argv) > 1 and sys.argv[1] == "bigref":
+        return make_bigref()
     rng = random.Random(20261003)
     d = os.path.join(HERE, "g1")
     os.makedirs(d, exist_ok=True)

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported(lib):
     declared = sorted(set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", hdr)))
     assert declared == sorted(b.SYMBOLS)
     inline = set(re.findall(r"static inline [a-z0-9_ ]+?\b(cs_[a-z0-9_]+)\s*\(", hdr))   # helpers that live in the header itself
-    assert inline == {"cs_unpack_mem", "cs_mem_seed_count"}
+    assert inline == {"cs_unpack_mem", "cs_mem_seed_count", "cs_packed_seed_rbeg"}
     for name in declared:
         if name not in inline:
             assert hasattr(lib, name), name
@@ -92,7 +92,8 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
     import subprocess
     import compseed_amd.binding as b
     structs = {"cs_index_view_t": b.IndexView, "cs_params_t": b.Params, "cs_result_t": b.CResult, "cs_stats_t": b.Stats,
-               "cs_engine_options_t": b.EngineOptions, "cs_traffic_t": b.Traffic, "cs_digest_t": b.Digest, "cs_packed_result_t": b.CPacked}
+               "cs_engine_options_t": b.EngineOptions, "cs_traffic_t": b.Traffic, "cs_digest_t": b.Digest, "cs_packed_result_t": b.CPacked, "cs_ext_params_t": b.ExtParams, "cs_ext_stats_t": b.ExtStats,
+               "cs_index_check_t": b.IndexCheck}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {']
     for cname, st in structs.items():
         src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -108,13 +109,22 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
         assert int(got[cname]) == ctypes.sizeof(st), cname
         for fname, _ in st._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
+    # the two array-element structs of the extension entry points are numpy dtypes on the Python side
+    for cname, dt in (("cs_ext_pair_t", b.EXT_PAIR_DT), ("cs_ext_result_t", b.EXT_RES_DT)):
+        src2 = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {', 'printf("%%zu\\n", sizeof(%s));' % cname]
+        src2 += ['printf("%%zu\\n", offsetof(%s, %s));' % (cname, f) for f in dt.names] + ["return 0; }"]
+        c2 = tmp_path / (cname + ".c"); c2.write_text("\n".join(src2))
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(tmp_path / cname), str(c2)], check=True)
+        nums = [int(x) for x in subprocess.run([str(tmp_path / cname)], capture_output=True, text=True, check=True).stdout.split()]
+        assert nums[0] == dt.itemsize and nums[1:] == [dt.fields[f][1] for f in dt.names], cname
 
 
 def test_product_reads_no_environment_switches():
     """configuration goes through cs_params_t / cs_engine_options_t, not through getenv"""
     for base, _, files in os.walk(os.path.join(ROOT, "compseed_amd", "csrc")):
         for f in files:
-            assert "getenv" not in open(os.path.join(base, f), errors="replace").read(), f
+            if f.endswith((".hip", ".hpp", ".cpp", ".h", ".c")):
+                assert "getenv" not in open(os.path.join(base, f), errors="replace").read(), f
 
 
 def test_product_does_not_touch_the_oracle():

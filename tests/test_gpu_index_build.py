@@ -89,3 +89,40 @@ def test_index_from_fasta_writes_all_five_files_like_bwaidx(tmp_path):
     ca.build_index_from_fasta(os.path.join(_data.GOLD, "ref.fa.gz"), str(tmp_path / "idx"), 0)
     for ext in ("bwt", "sa", "pac", "ann", "amb"):
         assert hashlib.md5(open(tmp_path / ("idx." + ext), "rb").read()).hexdigest() == man["g1/ref." + ext], ext
+
+
+def test_index_from_fasta_at_bwaidx_large_genome_branch(tmp_path):
+    """64 Mbp in three contigs (tests/_data.bigref_fasta): above 50 M packed bases the reference's bwaidx builds the BWT with bwt_bwtgen2 instead of
+    the in-memory sort (FM_index/index_main.c:277-283).  Its five files' md5s are in tests/golden/c2/config2.json (make_golden.py bigref); the GPU
+    builder must reproduce every one of them -- and the engine's own check of the result must be clean."""
+    import compseed_amd as ca
+    gold = json.load(open(os.path.join(_data.HERE, "golden", "c2", "config2.json")))
+    fa = str(tmp_path / "big.fa")
+    assert _data.bigref_fasta(fa) == gold["bases"]
+    assert hashlib.md5(open(fa, "rb").read()).hexdigest() == gold["fasta_md5"]            # the same genome as the one bwaidx indexed
+    ca.build_index_from_fasta(fa, str(tmp_path / "big"), 0)
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert hashlib.md5(open(tmp_path / ("big." + ext), "rb").read()).hexdigest() == gold["index_md5"][ext], ext
+    ix = ca.Index.load(str(tmp_path / "big"))
+    eng = ca.Engine(ix, 0)
+    chk = eng.check_index()                                                                # (no genome on the device here: everything but the text comparison)
+    assert chk["rows_checked"] == 2 * gold["bases"] and chk["text_checked"] == 0
+    assert all(chk[k] == 0 for k in ("order_violations", "isa_violations", "bwt_violations", "sampled_sa_violations", "undecided_rows")), chk
+    eng.close(); ix.close()
+
+
+def test_index_check_notices_a_corrupted_index():
+    """the checker is not vacuous: swap two sampled SA entries / flip BWT bases of the fixture and the counts are non-zero"""
+    import compseed_amd as ca
+    f = _data.load_bwt_files()
+    good = ca.Index.from_arrays(f["primary"], f["L2"], f["bwt"], f["sa"], f["sa_intv"])
+    e = ca.Engine(good, 0)
+    c = e.check_index()
+    assert all(c[k] == 0 for k in ("order_violations", "isa_violations", "bwt_violations", "sampled_sa_violations", "undecided_rows"))
+    e.close(); good.close()
+    sa = f["sa"].copy(); sa[[100, 2000]] = sa[[2000, 100]]
+    bad = ca.Index.from_arrays(f["primary"], f["L2"], f["bwt"], sa, f["sa_intv"])
+    e = ca.Engine(bad, 0)
+    c = e.check_index()
+    assert c["order_violations"] + c["isa_violations"] + c["bwt_violations"] + c["sampled_sa_violations"] > 0
+    e.close(); bad.close()

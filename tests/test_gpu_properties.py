@@ -229,6 +229,8 @@ def test_repeat_rich_and_indel_workloads_at_500mbp():
     G = synth.make_genome(500_000_000, seed=20261004, device="cuda", **synth.PROFILES["repeat50"]["genome"])
     ix = ca.Index.build(G.cpu().numpy(), 0)
     eng = ca.Engine(ix, 0)
+    chk = eng.check_index(G.data_ptr(), G.numel())                                 # the repeat-rich index itself (deep LCPs: satellites, young families)
+    assert chk["text_checked"] == 1 and all(chk[k] == 0 for k in ("order_violations", "isa_violations", "bwt_violations", "sampled_sa_violations", "undecided_rows", "text_violations")), chk
     bw, sa = ix.arrays()
     v = ix.view
     o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
@@ -276,10 +278,15 @@ def test_full_baseline_size_properties():
     bases, off = synth.make_reads(G, n, 150, seed=777, p_sub=0.005, sort=True)
     # two more chunks of the same run for the streamed part at the end (BASELINE configs[2])
     extra = [synth.make_reads(G, n, 150, seed=778 + j, p_sub=0.005, sort=True, lo_frac=0.3 * (j + 1), hi_frac=0.3 * (j + 1) + 0.3)[0] for j in range(2)]
-    del G
-    torch.cuda.empty_cache()
     assert ix.view.seq_len + 1 > 2**32
     eng = ca.Engine(ix, 0)
+    # the index at the size it is used, checked independently of how it was built: recovered text == G + revcomp(G), all 6.2e9 neighbouring
+    # suffix pairs in order (compared on the text), ISA o SA = id, BWT characters, sampled SA (cs_engine_check_index)
+    chk = eng.check_index(G.data_ptr(), G.numel())
+    assert chk["rows_checked"] == 2 * G.numel() and chk["text_checked"] == 1
+    assert all(chk[k] == 0 for k in ("order_violations", "isa_violations", "bwt_violations", "sampled_sa_violations", "undecided_rows", "text_violations")), chk
+    del G
+    torch.cuda.empty_cache()
     bw, sa = ix.arrays()
     v = ix.view
     o = _oracle.OracleIndex.from_arrays(v.primary, [v.L2[i] for i in range(1, 5)], bw, sa, 32)
@@ -344,7 +351,7 @@ def test_full_baseline_size_properties():
             assert int(p["mem_off"].sum(dtype=np.uint64)) == c["mo_sum"]
             sel_m = np.concatenate([np.arange(int(p["mem_off"][r]), int(p["mem_off"][r + 1])) for r in ids.astype(np.int64)])
             sel_s = np.concatenate([np.arange(int(p["seed_off"][r]), int(p["seed_off"][r + 1])) for r in ids.astype(np.int64)])
-            assert np.array_equal(ca.unpack_mems16(p["mems"][sel_m]), c["mems"]) and np.array_equal(p["seed_rbeg"][sel_s], c["rbeg"]), i
+            assert np.array_equal(ca.unpack_mems16(p["mems"][sel_m]), c["mems"]) and np.array_equal(ca.packed_rbeg(p, sel_s), c["rbeg"]), i
         if i + 2 < n_chunks:
             eng.submit(chunks[(i + 2) % 3]["pin"], ho)
         done += n
