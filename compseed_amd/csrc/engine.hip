@@ -1393,7 +1393,11 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	// parts: contiguous read ranges of about pipeline_reads reads (one, if the batch is not much larger than that)
 	std::vector<HostJob> parts;
 	const int64_t per = e->opt.pipeline_reads > 0 ? e->opt.pipeline_reads : std::max<int64_t>(n_reads, 1);
-	const int64_t kparts = std::max<int64_t>(1, (n_reads + per / 2) / per);
+	// Parts exist to overlap upload, seeding and download INSIDE one batch.  When another batch is already in flight that overlap happens
+	// across batches (upload of n+1 and download of n-1 beside the seeding of n), and cutting the batch would only pay the fixed cost of a
+	// pass once more per part (~4 ms per extra part at 10 M reads): a batch submitted behind another one is seeded whole.
+	const bool streaming = hp.n_submitted.load() - hp.n_collected.load() >= 1 && !expand;
+	const int64_t kparts = streaming ? 1 : std::max<int64_t>(1, (n_reads + per / 2) / per);
 	size_t in_cap = 0, off_cap = 0;
 	for (int64_t i = 0; i < kparts; ++i) {
 		HostJob j; j.batch = id; j.part = (int)i; j.n_parts = (int)kparts; j.bases = bases; j.offsets = offsets; j.n_reads = n_reads;
