@@ -463,7 +463,7 @@ def main():
             reps = 3
 
             def timed(fn):
-                fn(); fn()                                    # warm-up: both pinned result slots / the host buffers are sized on first use
+                fn(); fn(); fn()                              # warm-up: the three pinned result slots / the host buffers are sized on first use
                 tp = time.perf_counter()
                 for _ in range(reps):
                     r_ = fn()
@@ -480,17 +480,22 @@ def main():
             ok_p = np.array_equal(ca.unpack_mems16(pm) if rp["mem_format"] == 1 else pm, want["mems"])
             if not args.no_sal:
                 ok_p = ok_p and np.array_equal(ca.packed_rbeg(rp, sel_s), want["seeds"]["rbeg"])
-            # a stream of batches, two in flight (cs_engine_submit / cs_engine_collect_packed): upload of batch n+1, seeding of batch n
+            # a stream of batches, three in flight (cs_engine_submit / cs_engine_collect_packed): upload of batch n+1, seeding of batch n
             # and download of batch n-1 overlap -- how the reference drives this stage (kt_pipeline, main.cpp:438)
-            nstream = 5
-            eng.submit(hb_pin, ho_all, par); eng.submit(hb_pin, ho_all, par)
-            eng.collect_packed(); eng.submit(hb_pin, ho_all, par)        # the first batch fills the pipeline: not timed
-            tp = time.perf_counter()
-            for i in range(nstream):
+            # steady state of a long stream: 16 batches go through, three kept in flight from the first to the last; the clock runs from the
+            # completion of the 5th to the completion of the 13th (8 batches) -- the pipeline is full before, during and after the timed window
+            # (filling it takes three batches, and a batch submitted to an idle engine is cut into parts: neither belongs to the rate)
+            n_total, first, nstream = 16, 4, 8
+            for _ in range(3):
+                eng.submit(hb_pin, ho_all, par)
+            for i in range(n_total):
                 rs_ = eng.collect_packed()
-                if i + 2 < nstream + 1:
+                if i == first:
+                    tp = time.perf_counter()
+                if i == first + nstream:
+                    dt_s = (time.perf_counter() - tp) / nstream
+                if i + 3 < n_total:
                     eng.submit(hb_pin, ho_all, par)
-            dt_s = (time.perf_counter() - tp) / nstream
             while True:
                 try:
                     rs_ = eng.collect_packed()
@@ -513,10 +518,10 @@ def main():
                 "note": "rank 0, whole call: reads_per_s = cs_engine_seed_batch (reads from pinned host memory in, cs_intv_t / cs_seed_t arrays in host memory "
                         "out: upload, seeding, download and the host-side expansion of the packed results overlapped over sub-batches); packed_reads_per_s = "
                         "cs_engine_seed_batch_packed (the 16-byte / 8-byte form a consumer unpacks while it copies per read anyway); pipelined_packed_reads_per_s "
-                        "= a stream of such batches with two in flight (cs_engine_submit / cs_engine_collect_packed), per batch; never `value`"}
+                        "= a stream of such batches with three in flight (cs_engine_submit / cs_engine_collect_packed), per batch; never `value`"}
             # SURVEY 8(d) defines the metric "incl. H2D/D2H of reads/results": these are the conforming figures, under a key that says so
             # (`value` is the device-resident rate the bench contract asks for)
-            out["reads_per_s_incl_pcie"] = {"pipelined_two_batches_in_flight": args.reads / dt_s, "one_blocking_call_packed": args.reads / dt_p,
+            out["reads_per_s_incl_pcie"] = {"pipelined_three_batches_in_flight": args.reads / dt_s, "one_blocking_call_packed": args.reads / dt_p,
                                             "one_blocking_call_expanded": args.reads / dt_x, "bit_exact_vs_oracle": bool(ok_x and ok_p)}
             if not (ok_x and ok_p):
                 all_ok = False

@@ -147,9 +147,9 @@ struct cs_engine {
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
 	size_t lep_arena_bytes = (size_t)32 << 30;
 	// host variants (seed_host_pipelined): copy streams, two input slots, two pack slots, pinned packed results, expanded results
-	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[2] = {nullptr, nullptr};
+	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[3] = {nullptr, nullptr, nullptr};
 	DevBuf<uint8_t> hp_in[2], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[2], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<uint32_t> hp_pk_rlo[2]; DevBuf<uint8_t> hp_pk_rhi[2]; // seeds: low words and fifth bytes of rbeg
-	PinBuf<uint64_t> hp_moff[2], hp_soff[2]; PinBuf<uint8_t> hp_mems[2]; PinBuf<uint32_t> hp_rlo[2]; PinBuf<uint8_t> hp_rhi[2]; // two pinned result slots
+	PinBuf<uint64_t> hp_moff[3], hp_soff[3]; PinBuf<uint8_t> hp_mems[3]; PinBuf<uint32_t> hp_rlo[3]; PinBuf<uint8_t> hp_rhi[3]; // three pinned result slots (slot = batch % 3)
 	struct HostPipe *hp = nullptr;
 	HostBuf<cs_intv_t> x_mems; HostBuf<cs_seed_t> x_seeds;
 	cs_stats_t st{};
@@ -453,7 +453,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (int k = 0; k < 2; ++k) { e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
-	for (int k = 0; k < 2; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
+	for (int k = 0; k < 3; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
 	e->x_mems.release(); e->x_seeds.release();
 	for (auto &ev : e->hp_ev_done) if (ev) (void)hipEventDestroy(ev);
 	for (auto &ev : e->hp_ev_pk) if (ev) (void)hipEventDestroy(ev);
@@ -1211,7 +1211,7 @@ struct HostPipe {
 	int in_free[2] = {1, 1};
 	std::atomic<uint64_t> n_submitted{0}, n_collected{0}; uint64_t parts_seen = 0; // (one submitting and one collecting thread may run at the same time)
 	long long handed = -1;               // batch whose pinned result slot the caller currently holds (until its next collect)
-	BatchState bs[2];
+	BatchState bs[3];                    // batch id % 3: up to three batches in flight
 };
 
 static void pipe_upload_thread(cs_engine *e)
@@ -1233,7 +1233,7 @@ static void pipe_upload_thread(cs_engine *e)
 		if (he == hipSuccess && j.offsets) { hipLaunchKernelGGL(rebase_words_kernel, dim3(1), dim3(1024), 0, e->s_up, e->hp_inoff[j.in_slot].p, (uint64_t)j.n + 1); he = hipGetLastError(); }
 		if (he == hipSuccess) he = hipStreamSynchronize(e->s_up);
 		std::lock_guard<std::mutex> lk(hp.mu);
-		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch & 1]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
+		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch % 3]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
 		hp.q_seed.push_back(j);
 		hp.cv.notify_all();
 	}
@@ -1251,11 +1251,11 @@ static void pipe_expand_thread(cs_engine *e)
 			if (hp.quit) return;
 			x = hp.q_x.front(); hp.q_x.pop_front(); hp.x_busy = true;
 		}
-		BatchState &b = hp.bs[x.batch & 1];
-		const int rs = (int)(x.batch & 1);
+		BatchState &b = hp.bs[x.batch % 3];
+		const int rs = (int)(x.batch % 3);
 		bool ok = hipEventSynchronize(x.ev) == hipSuccess;
 		if (ok) {
-			const double scale = x.last ? 1.0 : (double)b.n_reads / (double)(x.r0 + x.n) * 1.08; // room for the whole batch at the first growth
+			const double scale = x.last ? 1.0 : (double)b.n_reads / (double)(x.r0 + x.n) * ((x.r0 + x.n) * 4 < b.n_reads ? 1.2 : 1.08); // room for the whole batch at the first growth
 			ok = !e->x_mems.reserve((size_t)((double)(x.mem_base + x.nm) * scale) + 1, (size_t)x.mem_base) &&
 			     (!b.sal || !e->x_seeds.reserve((size_t)((double)(x.seed_base + x.ns) * scale) + 1, (size_t)x.seed_base));
 		}
@@ -1285,7 +1285,7 @@ static void pipe_seed_thread(cs_engine *e)
 			if (hp.quit) return;
 			j = hp.q_seed.front(); hp.q_seed.pop_front();
 		}
-		const int rs = (int)(j.batch & 1);
+		const int rs = (int)(j.batch % 3);
 		BatchState &b = hp.bs[rs];
 		int rc; { std::lock_guard<std::mutex> lk(hp.mu); rc = b.rc; }
 		std::string err;
@@ -1295,8 +1295,12 @@ static void pipe_seed_thread(cs_engine *e)
 		const size_t msz = j.pk16 ? 16 : 32;
 		const auto t0 = std::chrono::steady_clock::now();
 		if (rc == CS_OK) { rc = seed_device_impl(e, &j.par, j.n, e->hp_in[j.in_slot].p, e->hp_inoff[j.in_slot].p, j.nb, &nm, &ns); if (rc != CS_OK) err = g_err; }
-		if (e->opt.verbose) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %lld reads seeded in %.1f ms\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (long long)j.n,
-		                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		if (e->opt.verbose) { // (with the wall clock of the seeding thread: idle gaps between parts show which neighbour it waited for)
+			static const auto t_epoch = std::chrono::steady_clock::now();
+			const auto t1 = std::chrono::steady_clock::now();
+			fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %lld reads seeded in %.1f ms (from %.1f to %.1f ms)\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (long long)j.n,
+			        std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t0 - t_epoch).count(), std::chrono::duration<double, std::milli>(t1 - t_epoch).count());
+		}
 		{ std::lock_guard<std::mutex> lk(hp.mu); hp.in_free[j.in_slot] = 1; hp.cv.notify_all(); } // (the reads were converted into the engine's own buffer)
 		const uint64_t k = hp.parts_seen++;                 // running part number: pack slot k & 1, part events k % 4
 		const int ps = (int)(k & 1);
@@ -1305,7 +1309,7 @@ static void pipe_seed_thread(cs_engine *e)
 			// the pack buffers of this slot were last used by the part before the previous one: its download must be over
 			if (k >= 2) hipf(hipEventSynchronize(e->hp_ev_dn[(k - 2) % 4]), "waiting for a download");
 			// the batch that used this pinned result slot before may still be in the caller's hands: wait until it is given back
-			{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || hp.handed < 0 || (uint64_t)hp.handed == j.batch || ((uint64_t)hp.handed & 1) != (j.batch & 1); }); if (hp.quit) return; }
+			{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || hp.handed < 0 || (uint64_t)hp.handed == j.batch || (uint64_t)hp.handed % 3 != j.batch % 3; }); if (hp.quit) return; }
 			// (from here on the result slot is this batch's) offsets: one entry per read + 1
 			if (j.part == 0 && (e->hp_moff[rs].reserve((size_t)j.n_reads + 1) != CS_OK || (sal && e->hp_soff[rs].reserve((size_t)j.n_reads + 1) != CS_OK))) { rc = CS_ENOMEM; err = g_err; }
 			// pinned room for the whole batch: estimated from its first part, grown (keeping what has arrived) if that was too little
@@ -1313,7 +1317,7 @@ static void pipe_seed_thread(cs_engine *e)
 			if (need_m * msz > e->hp_mems[rs].cap || (sal && need_s > e->hp_rlo[rs].cap)) {
 				hipf(hipStreamSynchronize(e->s_down), "draining downloads before growing the result buffers");
 				{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || (hp.q_x.empty() && !hp.x_busy); }); if (hp.quit) return; } // the expander reads these buffers
-				const double scale = (double)j.n_reads / (double)(j.r0 + j.n) * 1.08;
+				const double scale = (double)j.n_reads / (double)(j.r0 + j.n) * ((j.r0 + j.n) * 4 < j.n_reads ? 1.2 : 1.08); // (a small first part predicts the batch less well)
 				if (rc == CS_OK && e->hp_mems[rs].reserve((size_t)((double)need_m * scale) * msz + 4096, true, (size_t)mem_base * msz) != CS_OK) { rc = CS_ENOMEM; err = g_err; }
 				if (rc == CS_OK && sal && (e->hp_rlo[rs].reserve((size_t)((double)need_s * scale) + 512, true, (size_t)seed_base) != CS_OK ||
 				                            e->hp_rhi[rs].reserve((size_t)((double)need_s * scale) + 512, true, (size_t)seed_base) != CS_OK)) { rc = CS_ENOMEM; err = g_err; }
@@ -1376,7 +1380,7 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	HIP_TRY(hipSetDevice(e->device));
 	if (!e->hp) e->hp = new HostPipe();
 	HostPipe &hp = *e->hp;
-	if (hp.n_submitted.load() - hp.n_collected.load() >= 2) return fail(CS_EINVAL, "cs_engine_submit: two batches are in flight already, collect one first");
+	if (hp.n_submitted.load() - hp.n_collected.load() >= 3) return fail(CS_EINVAL, "cs_engine_submit: three batches are in flight already, collect one first");
 	uint64_t n_bases = 0, max_len = 0;
 	if (n_reads > 0) {
 		if (offsets[0] != 0) return fail(CS_EINVAL, "offsets[0] must be 0");
@@ -1389,19 +1393,34 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 		if (max_len >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
 	}
 	const uint64_t id = hp.n_submitted.load();
-	const int rs = (int)(id & 1);
+	const int rs = (int)(id % 3);
 	// parts: contiguous read ranges of about pipeline_reads reads (one, if the batch is not much larger than that)
 	std::vector<HostJob> parts;
 	const int64_t per = e->opt.pipeline_reads > 0 ? e->opt.pipeline_reads : std::max<int64_t>(n_reads, 1);
-	// Parts exist to overlap upload, seeding and download INSIDE one batch.  When another batch is already in flight that overlap happens
-	// across batches (upload of n+1 and download of n-1 beside the seeding of n), and cutting the batch would only pay the fixed cost of a
-	// pass once more per part (~4 ms per extra part at 10 M reads): a batch submitted behind another one is seeded whole.
-	const bool streaming = hp.n_submitted.load() - hp.n_collected.load() >= 1 && !expand;
-	const int64_t kparts = streaming ? 1 : std::max<int64_t>(1, (n_reads + per / 2) / per);
+	// Parts exist to overlap upload, seeding and download INSIDE one batch, and each part pays the fixed cost of a pass (two passes over
+	// 5 M reads take ~8 ms longer than one over 10 M).  When other batches are in flight the overlap comes from them -- upload of n+1 and
+	// download of n-1 beside the seeding of n -- so a batch submitted behind another one is seeded whole.  This needs THREE batches in
+	// flight to pay: with two, collect(n) returns when download(n) ends, only then can batch n+2 be submitted and uploaded, and download +
+	// upload (79 ms) is longer than the seeding of batch n+1 (55 ms): measured 92 ms per batch whole against 65 ms in parts.
+	const bool streaming = hp.n_submitted.load() - hp.n_collected.load() >= 2 && !expand;
+	// part boundaries.  A batch that has the engine to itself (a blocking call, the first batch of a stream) cannot hide the upload of its
+	// first part or the download of its last one behind anything, so those two are made small (0.3 of the nominal part) and the rest is
+	// cut into parts of about 0.7: 10 M reads at 5 M nominal = 1.5 / 3.5 / 3.5 / 1.5 M.
+	std::vector<int64_t> cut(1, 0);
+	const int64_t even = std::max<int64_t>(1, (n_reads + per / 2) / per);
+	if (streaming || even < 2) cut.push_back(n_reads);
+	else {
+		const int64_t h = std::max<int64_t>(1, std::min<int64_t>(n_reads / 4, per * 3 / 10)), rest = n_reads - 2 * h;
+		const int64_t km = std::max<int64_t>(1, (rest + per * 7 / 20) / std::max<int64_t>(1, per * 7 / 10));
+		cut.push_back(h);
+		for (int64_t i = 1; i <= km; ++i) cut.push_back(h + rest * i / km);
+		cut.push_back(n_reads);
+	}
+	const int64_t kparts = (int64_t)cut.size() - 1;
 	size_t in_cap = 0, off_cap = 0;
 	for (int64_t i = 0; i < kparts; ++i) {
 		HostJob j; j.batch = id; j.part = (int)i; j.n_parts = (int)kparts; j.bases = bases; j.offsets = offsets; j.n_reads = n_reads;
-		j.r0 = n_reads * i / kparts; j.n = n_reads * (i + 1) / kparts - j.r0;
+		j.r0 = cut[(size_t)i]; j.n = cut[(size_t)i + 1] - j.r0;
 		j.b0 = n_reads ? offsets[j.r0] : 0; j.nb = n_reads ? offsets[j.r0 + j.n] - j.b0 : 0;
 		j.par = *par; j.pk16 = (e->ix.seq_len >> 33) == 0 && max_len < (1u << 15); j.expand = expand;
 		in_cap = std::max<size_t>(in_cap, j.nb); off_cap = std::max<size_t>(off_cap, (size_t)j.n + 1);
@@ -1413,7 +1432,8 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 			// a reallocation frees buffers the other batch may still be using: not only while its parts are queued or being seeded
 			// (the input slots are given back right after seed_device_impl), but until the seeding thread has queued the pack kernels
 			// and downloads of its LAST part (parts_queued == parts_total) and those have drained (s_down below)
-			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[rs ^ 1].parts_queued == hp.bs[rs ^ 1].parts_total); });
+			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[(rs + 1) % 3].parts_queued == hp.bs[(rs + 1) % 3].parts_total &&
+			                                     hp.bs[(rs + 2) % 3].parts_queued == hp.bs[(rs + 2) % 3].parts_total); });
 			lk.unlock();
 			HIP_TRY(hipStreamSynchronize(e->stream));
 			HIP_TRY(hipStreamSynchronize(e->s_down));
@@ -1445,7 +1465,7 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 	HIP_TRY(hipSetDevice(e->device));
 	HostPipe &hp = *e->hp;
 	const uint64_t id = hp.n_collected.load();
-	const int rs = (int)(id & 1);
+	const int rs = (int)(id % 3);
 	BatchState &b = hp.bs[rs];
 	{
 		std::unique_lock<std::mutex> lk(hp.mu);

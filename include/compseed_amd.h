@@ -224,11 +224,13 @@ typedef struct {
 static inline int64_t cs_packed_seed_rbeg(const cs_packed_result_t *r, uint64_t i) { return (int64_t)((uint64_t)r->seed_rbeg_lo[i] | (uint64_t)r->seed_rbeg_hi[i] << 32); }
 int  cs_engine_seed_batch_packed(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                                  const uint8_t *bases, const uint64_t *offsets, cs_packed_result_t *out);
-/* The same as a two-deep pipeline across batches, the counterpart of the reference's kt_pipeline (main.cpp:438: read chunk n+1 while
- * chunk n is processed and chunk n-1 written): cs_engine_submit queues a batch and returns at once (at most two in flight; the caller's
- * buffers must stay untouched until the batch is collected), cs_engine_collect_packed blocks until the OLDEST submitted batch is complete.
- * With two batches kept submitted the upload of batch n+1, the seeding of batch n and the download of batch n-1 overlap, and throughput is
- * that of the slowest of the three instead of their sum.  A collected result stays valid until the next collect or blocking seed call.
+/* The same as a pipeline across batches, the counterpart of the reference's kt_pipeline (main.cpp:438: read chunk n+1 while chunk n is
+ * processed and chunk n-1 written): cs_engine_submit queues a batch and returns at once (at most THREE in flight; the caller's buffers
+ * must stay untouched until the batch is collected), cs_engine_collect_packed blocks until the OLDEST submitted batch is complete.  With
+ * batches kept submitted the upload of batch n+1, the seeding of batch n and the download of batch n-1 overlap, and throughput is that of the
+ * slowest of the three instead of their sum.  Two in flight (what a two-thread kt_pipeline gives) leaves a gap: batch n+2 can only be
+ * submitted when collect(n) has returned, i.e. after download(n), and its upload then has to fit into what is left of the seeding of n+1;
+ * a caller that can keep three submitted closes it.  A collected result stays valid until the next collect or blocking seed call.
  * While batches are in flight the engine's other entry points that use the device return CS_EINVAL (cs_engine_reset_stats does nothing).
  * Threads: cs_engine_submit may be called from ONE thread while cs_engine_collect_packed runs on ONE other thread (the reader and the
  * processing step of a kt_pipeline, main.cpp:60-126); everything else on an engine needs the caller's own serialisation. */

@@ -512,7 +512,7 @@ def test_packed_falls_back_to_full_records_for_long_reads(eng):
 
 
 def test_submit_collect_pipeline_across_batches():
-    """cs_engine_submit / cs_engine_collect_packed: two batches in flight, results come back in submission order and equal the goldens;
+    """cs_engine_submit / cs_engine_collect_packed: three batches in flight, results come back in submission order and equal the goldens;
     a collected result stays intact while later batches are submitted, seeded and downloaded; misuse is an error code"""
     import compseed_amd as ca
     ix = ca.Index.load(_data.PREFIX)
@@ -526,9 +526,9 @@ def test_submit_collect_pipeline_across_batches():
         data.append((z, pin, off))
     with pytest.raises(ca.CSError):
         e.collect_packed()                                   # nothing submitted
-    e.submit(data[0][1], data[0][2]); e.submit(data[1][1], data[1][2])
+    e.submit(data[0][1], data[0][2]); e.submit(data[1][1], data[1][2]); e.submit(data[2][1], data[2][2])
     with pytest.raises(ca.CSError):
-        e.submit(data[2][1], data[2][2])                     # two in flight already
+        e.submit(data[3][1], data[3][2])                     # three in flight already
     with pytest.raises(ca.CSError):
         e.seed_batch(data[2][1], data[2][2])                 # blocking calls refuse while batches are in flight
     held = None
@@ -540,8 +540,8 @@ def test_submit_collect_pipeline_across_batches():
         mems, seeds = _expand_packed(p)
         assert np.array_equal(p["mem_off"], z["mem_off"]) and np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), z["mems"]), runs[i]
         assert np.array_equal(seeds["rbeg"], z["seed_rbeg"]) and np.array_equal(p["seed_off"], z["seed_off"]), runs[i]
-        if i + 2 < len(runs):
-            e.submit(data[i + 2][1], data[i + 2][2])         # keep two in flight
+        if i + 3 < len(runs):
+            e.submit(data[i + 3][1], data[i + 3][2])         # keep three in flight
             import time
             time.sleep(0.05)                                 # let the next batches run: the held result must not change under us
             m2, s2 = _expand_packed(p)
@@ -604,7 +604,9 @@ def test_submit_growing_batches_while_the_other_is_in_flight():
         for j, sz in enumerate(sizes):
             k0 = (j * 131 + rnd * 17) % (n - sz + 1)
             jobs.append(sub(k0, k0 + sz))
-        e.submit(jobs[0][0], jobs[0][1]); e.submit(jobs[1][0], jobs[1][1])
+        depth = 2 + (rnd & 1)                                                      # two in flight (what the reference's kt_pipeline keeps) or three
+        for j in range(depth):
+            e.submit(jobs[j][0], jobs[j][1])
         for i in range(len(jobs)):
             p = e.collect_packed()
             k0, k1 = jobs[i][2]
@@ -612,7 +614,7 @@ def test_submit_growing_batches_while_the_other_is_in_flight():
             assert np.array_equal(p["mem_off"].astype(np.int64), mo[k0:k1 + 1] - mo[k0]), (rnd, i)
             assert np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), want_m[mo[k0]:mo[k1]]), (rnd, i)
             assert np.array_equal(seeds["rbeg"], z["seed_rbeg"][so[k0]:so[k1]]), (rnd, i)
-            if i + 2 < len(jobs):
-                e.submit(jobs[i + 2][0], jobs[i + 2][1])
+            if i + depth < len(jobs):
+                e.submit(jobs[i + depth][0], jobs[i + depth][1])
         e.close()
     ix.close()

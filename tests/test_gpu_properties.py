@@ -325,7 +325,7 @@ def test_full_baseline_size_properties():
         assert st0["reseed_text_calls"] == 0 and st0["r3_text_seeds"] == 0 and st0["bwt_calls"] == st0["bwt_queries"]
         assert eng.result_digest() == d_on, kw                                     # all 10 M reads, all four arrays
         eng.reset_stats()
-    # ---- BASELINE configs[2] shape: ~600 M reads streamed through ONE GPU as 60 chunks of 10 M, two chunks in flight (cs_engine_submit /
+    # ---- BASELINE configs[2] shape: ~600 M reads streamed through ONE GPU as 60 chunks of 10 M, three chunks in flight (cs_engine_submit /
     # cs_engine_collect_packed), the chunks coming from pinned host buffers as a reader would deliver them.  Three distinct chunks are cycled
     # (generating 90 GB of distinct text would only time the generator); every collected chunk must be exactly the result the device
     # variant gives for that chunk: counts, offsets, and the packed mems / seeds of a strided sample.
@@ -341,7 +341,7 @@ def test_full_baseline_size_properties():
     assert len({c["n_mems"] for c in chunks}) == 3                                # the three chunks really differ
     import time
     n_chunks, done = 60, 0
-    eng.submit(chunks[0]["pin"], ho); eng.submit(chunks[1]["pin"], ho)
+    eng.submit(chunks[0]["pin"], ho); eng.submit(chunks[1]["pin"], ho); eng.submit(chunks[2]["pin"], ho)   # three in flight
     t0 = time.perf_counter()
     for i in range(n_chunks):
         p = eng.collect_packed()
@@ -352,8 +352,8 @@ def test_full_baseline_size_properties():
             sel_m = np.concatenate([np.arange(int(p["mem_off"][r]), int(p["mem_off"][r + 1])) for r in ids.astype(np.int64)])
             sel_s = np.concatenate([np.arange(int(p["seed_off"][r]), int(p["seed_off"][r + 1])) for r in ids.astype(np.int64)])
             assert np.array_equal(ca.unpack_mems16(p["mems"][sel_m]), c["mems"]) and np.array_equal(ca.packed_rbeg(p, sel_s), c["rbeg"]), i
-        if i + 2 < n_chunks:
-            eng.submit(chunks[(i + 2) % 3]["pin"], ho)
+        if i + 3 < n_chunks:
+            eng.submit(chunks[(i + 3) % 3]["pin"], ho)
         done += n
     dt = time.perf_counter() - t0
     print("streamed %d reads in %.2f s: %.1f M reads/s incl. PCIe" % (done, dt, done / dt / 1e6))
