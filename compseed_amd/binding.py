@@ -18,7 +18,8 @@ SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", 
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync", "cs_packed_seed_rbeg", "cs_engine_check_index",
-           "cs_ext_params_default", "cs_extender_create", "cs_extender_destroy", "cs_extend_batch", "cs_extend_batch_device", "cs_extender_stats"]
+           "cs_ext_params_default", "cs_extender_create", "cs_extender_destroy", "cs_extend_batch", "cs_extend_batch_device", "cs_extender_stats",
+           "cs_extender_upload", "cs_extend_batch_resident", "cs_aln_params_default", "cs_aligner_create", "cs_aligner_destroy", "cs_extend_chains", "cs_aligner_stats"]
 
 
 class CSError(RuntimeError):
@@ -126,6 +127,26 @@ class ExtParams(C.Structure):
         for i in range(25):
             self.mat[i] = int(mat[i])
         self.o_del, self.e_del, self.o_ins, self.e_ins, self.zdrop, self.end_bonus = o_del, e_del, o_ins, e_ins, zdrop, end_bonus
+
+
+ALNREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4"),
+                      ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"), ("chain", "<i4")])   # cs_alnreg_t
+
+
+class AlnParams(C.Structure):
+    """cs_aln_params_t: the mem_opt_t fields the extension stage reads (-A -B -O -E -L -w -d)"""
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "zdrop")]
+
+    def __init__(self, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, pen_clip5=5, pen_clip3=5, w=100, zdrop=100):
+        super().__init__(a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop)
+
+
+class CAlnResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_regs", C.c_uint64), ("reg_off", C.c_void_p), ("regs", C.c_void_p)]
+
+
+class AlnStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("reads", "regions", "pairs", "retries", "purged", "launches")]
 
 
 class IndexCheck(C.Structure):
@@ -286,6 +307,15 @@ def load_library():
     L.cs_extend_batch.argtypes = [vp, i64, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int32, vp]
     L.cs_extend_batch_device.argtypes = [vp, i64, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int32, vp]
     L.cs_extender_stats.argtypes = [vp, C.POINTER(ExtStats)]
+    L.cs_extender_upload.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+    L.cs_extend_batch_resident.argtypes = [vp, i64, vp, C.c_int32, vp]
+    L.cs_aln_params_default.argtypes = [C.POINTER(AlnParams)]
+    L.cs_aln_params_default.restype = None
+    L.cs_aligner_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(AlnParams), C.POINTER(vp)]
+    L.cs_aligner_destroy.argtypes = [vp]
+    L.cs_aligner_destroy.restype = None
+    L.cs_extend_chains.argtypes = [vp, C.POINTER(CChainResult), vp, vp, vp, C.POINTER(CAlnResult)]
+    L.cs_aligner_stats.argtypes = [vp, C.POINTER(AlnStats)]
     _lib = L
     return L
 
@@ -709,6 +739,43 @@ class Extender:
     def close(self):
         if self.h:
             self.L.cs_extender_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Aligner:
+    """cs_aligner_t: the extension stage as a whole (the reference's mem_chain2aln_across_reads_V2): chains in, alignment regions out"""
+
+    def __init__(self, prefix, device=0, params=None):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _check(self.L.cs_aligner_create(os.fsencode(prefix), device, C.byref(params) if params is not None else None, C.byref(self.h)))
+
+    def extend_chains(self, chain_off, chains, cseed_off, cseeds, bases, read_offsets, cseed_score=None):
+        """chains as Chainer.chain returns them (or the caller's own, e.g. filtered); returns dict(reg_off, regs (ALNREG_DT)), copies"""
+        chain_off = np.ascontiguousarray(chain_off, dtype=np.uint64); cseed_off = np.ascontiguousarray(cseed_off, dtype=np.uint64)
+        chains = np.ascontiguousarray(chains, dtype=CHAIN_DT); cseeds = np.ascontiguousarray(cseeds, dtype=SEED_DT)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8); ro = np.ascontiguousarray(read_offsets, dtype=np.uint64)
+        sc = None if cseed_score is None else np.ascontiguousarray(cseed_score, dtype=np.int32)
+        cr = CChainResult(chain_off.size - 1, chains.size, cseeds.size, chain_off.ctypes.data, chains.ctypes.data if chains.size else None, cseed_off.ctypes.data,
+                          cseeds.ctypes.data if cseeds.size else None)
+        out = CAlnResult()
+        _check(self.L.cs_extend_chains(self.h, C.byref(cr), sc.ctypes.data if sc is not None and sc.size else None, bases.ctypes.data if bases.size else None, ro.ctypes.data, C.byref(out)))
+        return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1), regs=_view(out.regs, ALNREG_DT, int(out.n_regs)))
+
+    def stats(self):
+        st = AlnStats()
+        _check(self.L.cs_aligner_stats(self.h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in AlnStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.L.cs_aligner_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

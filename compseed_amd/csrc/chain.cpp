@@ -20,8 +20,6 @@
 #include <unordered_map>
 #include <vector>
 
-struct cs_refseq_view { int64_t l_pac; std::vector<int64_t> offset; std::vector<int32_t> len; std::vector<uint8_t> is_alt; };
-
 struct cs_chainer { cs_refseq_view ref; std::vector<cs_chain_t> chains; std::vector<uint64_t> chain_off, cseed_off; std::vector<cs_seed_t> cseeds; };
 
 namespace {
@@ -186,16 +184,14 @@ void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs
 // contig table from <prefix>.ann (bns_restore_core, bntseq.c:97-140: "l_pac n_seqs seed", then per sequence "gi name [comment]" and
 // "offset len n_ambs"), ALT flags from <prefix>.alt where that file exists (bns_restore, bntseq.c:178-207: the first field of every
 // line that does not start with '@' names an ALT contig; a last line without a newline is not looked at)
-extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
+int cs_load_contigs_(const char *prefix, cs_refseq_view &ref)
 {
-	if (!prefix || !out) return cs_fail_(CS_EINVAL, "cs_chainer_create: null argument");
-	*out = nullptr;
 	FILE *fp = fopen((std::string(prefix) + ".ann").c_str(), "r");
 	if (!fp) return cs_fail_(CS_EIO, std::string("cannot read ") + prefix + ".ann");
-	cs_chainer *c = new cs_chainer();
+	ref = cs_refseq_view();
 	long long l_pac = 0; int n_seqs = 0; unsigned seed = 0;
 	bool ok = fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) == 3 && n_seqs > 0;
-	c->ref.l_pac = l_pac;
+	ref.l_pac = l_pac;
 	std::vector<char> line(1 << 16);
 	std::unordered_map<std::string, int> by_name; // (the reference's hash keeps the last contig of a repeated name)
 	if (ok) ok = fgets(line.data(), (int)line.size(), fp) != nullptr; // rest of the first line
@@ -205,22 +201,31 @@ extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
 		ok = fscanf(fp, "%u%8191s", &gi, name.data()) == 2;                               // "gi name", then the comment up to the end of the line
 		ok = ok && fgets(line.data(), (int)line.size(), fp) != nullptr;
 		ok = ok && fscanf(fp, "%lld%d%d", &off, &len, &n_ambs) == 3;
-		if (ok) { by_name[name.data()] = i; c->ref.offset.push_back(off); c->ref.len.push_back(len); ok = fgets(line.data(), (int)line.size(), fp) != nullptr || i == n_seqs - 1; }
+		if (ok) { by_name[name.data()] = i; ref.offset.push_back(off); ref.len.push_back(len); ok = fgets(line.data(), (int)line.size(), fp) != nullptr || i == n_seqs - 1; }
 	}
 	fclose(fp);
-	if (!ok) { delete c; return cs_fail_(CS_EIO, std::string(prefix) + ".ann is malformed"); }
-	c->ref.is_alt.assign((size_t)n_seqs, 0);
+	if (!ok) return cs_fail_(CS_EIO, std::string(prefix) + ".ann is malformed");
+	ref.is_alt.assign((size_t)n_seqs, 0);
 	if ((fp = fopen((std::string(prefix) + ".alt").c_str(), "r")) != nullptr) {
 		std::string field; bool in_field = true; int ch;
 		while ((ch = fgetc(fp)) != EOF) {
 			if (ch == '\n') {
-				if (in_field || !field.empty()) { if (!field.empty() && field[0] != '@') { auto it = by_name.find(field); if (it != by_name.end()) c->ref.is_alt[(size_t)it->second] = 1; } }
+				if (in_field || !field.empty()) { if (!field.empty() && field[0] != '@') { auto it = by_name.find(field); if (it != by_name.end()) ref.is_alt[(size_t)it->second] = 1; } }
 				field.clear(); in_field = true;
 			} else if (in_field && (ch == '\t' || ch == '\r')) in_field = false;
 			else if (in_field) field.push_back((char)ch);
 		}
 		fclose(fp);
 	}
+	return CS_OK;
+}
+extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
+{
+	if (!prefix || !out) return cs_fail_(CS_EINVAL, "cs_chainer_create: null argument");
+	*out = nullptr;
+	cs_chainer *c = new cs_chainer();
+	const int rc = cs_load_contigs_(prefix, c->ref);
+	if (rc != CS_OK) { delete c; return rc; }
 	*out = c;
 	return CS_OK;
 }

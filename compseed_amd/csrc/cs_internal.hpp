@@ -11,3 +11,7 @@ struct cs_index { // host copy of an index: the arrays behind a cs_index_view_t
 };
 
 int cs_fail_(int code, const std::string &msg); // records the calling thread's error message, returns code
+
+// contig table of an index (<prefix>.ann, ALT flags from <prefix>.alt): shared by the chainer and the extension driver
+struct cs_refseq_view { int64_t l_pac; std::vector<int64_t> offset; std::vector<int32_t> len; std::vector<uint8_t> is_alt; };
+int cs_load_contigs_(const char *prefix, cs_refseq_view &ref);

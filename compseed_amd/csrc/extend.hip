@@ -210,6 +210,7 @@ struct cs_extender {
 	cse::ExtParams P{};
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	void *d_pairs = nullptr, *d_q = nullptr, *d_t = nullptr, *d_out = nullptr, *d_scratch = nullptr; size_t c_pairs = 0, c_q = 0, c_t = 0, c_out = 0, c_scratch = 0;
+	uint64_t res_q = 0, res_t = 0;                         // bytes of the sequence buffers uploaded by cs_extender_upload
 	unsigned long long *d_ctr = nullptr, *h_ctr = nullptr; // device words: [0] skipped pairs [1] cells [2] rows [3] longest query; [4..7] hold the matrix
 	cs_ext_stats_t st{};
 };
@@ -342,6 +343,40 @@ extern "C" int cs_extend_batch(cs_extender_t *x, int64_t n_pairs, const cs_ext_p
 	const int rc = extend_device(x, n_pairs, (const cs_ext_pair_t *)x->d_pairs, (const uint8_t *)x->d_q, q_bytes, (const uint8_t *)x->d_t, t_bytes, w, (cs_ext_result_t *)x->d_out);
 	const std::string keep = rc != CS_OK ? std::string(cs_last_error()) : std::string();
 	if (rc == CS_OK || rc == CS_EINVAL) { // (CS_EINVAL from skipped pairs: the other results are valid and are delivered)
+		hipError_t e = hipMemcpyAsync(out, x->d_out, (size_t)n_pairs * sizeof(cs_ext_result_t), hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess) e = hipStreamSynchronize(s);
+		if (e != hipSuccess) { (void)hipGetLastError(); return cs_fail_(CS_EDEVICE, hipGetErrorString(e)); }
+	}
+	if (rc != CS_OK) return cs_fail_(rc, keep);
+	return CS_OK;
+}
+
+// The band retries of the reference extend the SAME sequences again with another pair list (comp_seed.cpp:1717-1776): the two buffers
+// are uploaded once and stay resident in the extender; every try then moves only its pairs in and its results out.
+extern "C" int cs_extender_upload(cs_extender_t *x, const uint8_t *qbuf, uint64_t q_bytes, const uint8_t *tbuf, uint64_t t_bytes)
+{
+	if (!x || (q_bytes && !qbuf) || (t_bytes && !tbuf)) return cs_fail_(CS_EINVAL, "cs_extender_upload: bad argument");
+	HIP_TRYX(hipSetDevice(x->device));
+	if (int rc = grow(&x->d_q, &x->c_q, (size_t)q_bytes + 64)) return rc;
+	if (int rc = grow(&x->d_t, &x->c_t, (size_t)t_bytes + 64)) return rc;
+	if (q_bytes) HIP_TRYX(hipMemcpyAsync(x->d_q, qbuf, (size_t)q_bytes, hipMemcpyHostToDevice, x->stream));
+	if (t_bytes) HIP_TRYX(hipMemcpyAsync(x->d_t, tbuf, (size_t)t_bytes, hipMemcpyHostToDevice, x->stream));
+	HIP_TRYX(hipStreamSynchronize(x->stream));
+	x->res_q = q_bytes; x->res_t = t_bytes;
+	return CS_OK;
+}
+extern "C" int cs_extend_batch_resident(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *pairs, int32_t w, cs_ext_result_t *out)
+{
+	if (!x || n_pairs < 0 || w < 0 || (n_pairs > 0 && (!pairs || !out))) return cs_fail_(CS_EINVAL, "cs_extend_batch_resident: bad argument");
+	if (n_pairs == 0) return CS_OK;
+	HIP_TRYX(hipSetDevice(x->device));
+	if (int rc = grow(&x->d_pairs, &x->c_pairs, (size_t)n_pairs * sizeof(cs_ext_pair_t))) return rc;
+	if (int rc = grow(&x->d_out, &x->c_out, (size_t)n_pairs * sizeof(cs_ext_result_t))) return rc;
+	hipStream_t s = x->stream;
+	HIP_TRYX(hipMemcpyAsync(x->d_pairs, pairs, (size_t)n_pairs * sizeof(cs_ext_pair_t), hipMemcpyHostToDevice, s));
+	const int rc = extend_device(x, n_pairs, (const cs_ext_pair_t *)x->d_pairs, (const uint8_t *)x->d_q, x->res_q, (const uint8_t *)x->d_t, x->res_t, w, (cs_ext_result_t *)x->d_out);
+	const std::string keep = rc != CS_OK ? std::string(cs_last_error()) : std::string();
+	if (rc == CS_OK || rc == CS_EINVAL) {
 		hipError_t e = hipMemcpyAsync(out, x->d_out, (size_t)n_pairs * sizeof(cs_ext_result_t), hipMemcpyDeviceToHost, s);
 		if (e == hipSuccess) e = hipStreamSynchronize(s);
 		if (e != hipSuccess) { (void)hipGetLastError(); return cs_fail_(CS_EDEVICE, hipGetErrorString(e)); }

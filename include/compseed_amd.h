@@ -311,6 +311,31 @@ int  cs_extend_batch(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *pai
 int  cs_extend_batch_device(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *d_pairs, const uint8_t *d_qbuf, uint64_t q_bytes,
                             const uint8_t *d_tbuf, uint64_t t_bytes, int32_t w, cs_ext_result_t *d_out);
 int  cs_extender_stats(const cs_extender_t *x, cs_ext_stats_t *st);
+/* the band retries extend the same sequences again with another pair list: upload the two buffers once, then run pair lists against them */
+int  cs_extender_upload(cs_extender_t *x, const uint8_t *qbuf, uint64_t q_bytes, const uint8_t *tbuf, uint64_t t_bytes);
+int  cs_extend_batch_resident(cs_extender_t *x, int64_t n_pairs, const cs_ext_pair_t *pairs, int32_t w, cs_ext_result_t *out);
+
+/* ---- the extension stage as a whole: mem_chain2aln_across_reads_V2 (mapping/comp_seed.cpp:1319-2237), chains in, alignment regions out.
+ *      For every seed of every chain (as the caller's chain filters left them: mem_chain_flt / mem_flt_chained_seeds, comp_seed.cpp:2364-2367,
+ *      are the caller's) a region is opened, extended left and then right by banded Smith-Waterman on the GPU -- band w, once more with 2w
+ *      where the alignment came within a quarter of the band's edge (MAX_BAND_TRY 2) --, and regions made redundant by an earlier region
+ *      of the read are marked qb = qe = -1 (the caller drops them as comp_seed.cpp:2387-2393 does).  cs_alnreg_t holds the fields of
+ *      mem_alnreg_t this stage fills (comp_seed.h:106-125); `chain` is the index of the region's chain within its read.  Regions come in the
+ *      reference's order: chain by chain, seeds by descending score.  `chains`: the chains as a cs_chain_result_t -- cs_chain_batch's output or the caller's
+ *      own --, `cseed_score` the chained seeds' scores in the same order (NULL: score = len, what mem_chain leaves), `bases` / `read_offsets` the
+ *      batch's reads (ASCII or codes; a '-' is code 5 as in nst_nt4_table).  The aligner loads <prefix>.ann / .alt / .pac.  The result arrays
+ *      belong to the aligner and stay valid until its next call.  pen_clip5 must equal pen_clip3 for now. */
+typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop; } cs_aln_params_t;   /* mem_opt_t: -A -B -O -E -L -w -d */
+typedef struct { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0; float frac_rep; int32_t chain; } cs_alnreg_t;
+typedef struct { int64_t n_reads; uint64_t n_regs; const uint64_t *reg_off; const cs_alnreg_t *regs; } cs_aln_result_t;
+typedef struct { uint64_t reads, regions, pairs, retries, purged, launches; } cs_aln_stats_t;   /* pairs = extensions run incl. retries */
+typedef struct cs_aligner cs_aligner_t;
+void cs_aln_params_default(cs_aln_params_t *p);
+int  cs_aligner_create(const char *prefix, int device, const cs_aln_params_t *par /* NULL: defaults */, cs_aligner_t **out);
+void cs_aligner_destroy(cs_aligner_t *a);
+int  cs_extend_chains(cs_aligner_t *a, const cs_chain_result_t *chains, const int32_t *cseed_score, const uint8_t *bases,
+                      const uint64_t *read_offsets, cs_aln_result_t *out);
+int  cs_aligner_stats(const cs_aligner_t *a, cs_aln_stats_t *st);
 
 /* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array
  *      (sum over the array's 64-bit words w[i] of splitmix64(w[i] + i * 0x9E3779B97F4A7C15), mod 2^64), so that two runs over

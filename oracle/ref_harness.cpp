@@ -42,6 +42,24 @@ int tem_forward_sst(const mem_opt_t *opt, const uint8_t *seq, int len, int start
 typedef struct { size_t n, m; mem_chain_t *a; } mem_chain_v;
 mem_chain_v mem_chain(const mem_opt_t *opt, const bntseq_t *bns, int len, const std::vector<bwtintv_t> &mem, const std::vector<mem_seed_t> &seed);
 
+// the stage behind chaining (--aln): the reference's own chain filters and its batched extension driver, all with external linkage
+// (mapping/comp_seed.cpp:297, 393, 1319).  mem_cache is defined in the .cpp (comp_seed.cpp:1124-1148): the same layout is declared here so
+// that the harness can allocate the scratch the function expects exactly as memoryAlloc does (comp_seed.cpp:2444-2491).
+#include "mapping/bandedSWA.h"
+#include "mapping/macro.h"
+int mem_chain_flt(const mem_opt_t *opt, int n_chn, mem_chain_t *a);
+void mem_flt_chained_seeds(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, int l_query, const uint8_t *query, int n_chn, mem_chain_t *a);
+typedef struct {
+	SeqPair *seqPairArrayAux[MAX_THREADS], *seqPairArrayLeft128[MAX_THREADS], *seqPairArrayRight128[MAX_THREADS];
+	int64_t wsize[MAX_THREADS];
+	int64_t wsize_buf_ref[MAX_THREADS * CACHE_LINE], wsize_buf_qer[MAX_THREADS * CACHE_LINE];
+	uint8_t *seqBufLeftRef[MAX_THREADS * CACHE_LINE], *seqBufRightRef[MAX_THREADS * CACHE_LINE], *seqBufLeftQer[MAX_THREADS * CACHE_LINE], *seqBufRightQer[MAX_THREADS * CACHE_LINE];
+	int32_t *lim[MAX_THREADS];
+	int64_t wsize_mem[MAX_THREADS];
+} mem_cache;
+void mem_chain2aln_across_reads_V2(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *seq_, int nseq, mem_chain_v *chain_ar,
+                                   mem_alnreg_v *av_v, mem_cache *mmc, int tid);
+
 static bool by_info(const bwtintv_t &a, const bwtintv_t &b) { return a.info < b.info; }
 
 // mapping/bwamem.c:218-272 replayed with the public bwt.h entry points
@@ -232,7 +250,7 @@ int main(int argc, char **argv)
 	}
 	mem_opt_t *opt = mem_opt_init();
 	int batch = BATCH_SIZE;
-	const char *prim_fn = 0, *chain_fn = 0; long prim_n = 0; uint64_t prim_seed = 1; int time_threads = 0;
+	const char *prim_fn = 0, *chain_fn = 0, *aln_fn = 0; long prim_n = 0; uint64_t prim_seed = 1; int time_threads = 0;
 	for (int i = 4; i < argc; i++) {
 		std::string a = argv[i];
 		if (a == "-k") opt->min_seed_len = atoi(argv[++i]);
@@ -243,12 +261,13 @@ int main(int argc, char **argv)
 		else if (a == "-B") batch = atoi(argv[++i]);
 		else if (a == "--prim") { prim_fn = argv[++i]; prim_n = atol(argv[++i]); prim_seed = strtoull(argv[++i], 0, 10); }
 		else if (a == "--chains") chain_fn = argv[++i];
+		else if (a == "--aln") aln_fn = argv[++i];
 		else if (a == "--time") time_threads = atoi(argv[++i]);
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
 	}
 	if (batch < 1 || batch > BATCH_SIZE) { fprintf(stderr, "batch must be in [1,%d]\n", BATCH_SIZE); return 1; }
 	bwa_verbose = 1;
-	bwaidx_t *idx = bwa_idx_load(argv[1], chain_fn ? (BWA_IDX_BWT | BWA_IDX_BNS) : BWA_IDX_BWT);
+	bwaidx_t *idx = bwa_idx_load(argv[1], aln_fn ? BWA_IDX_ALL : chain_fn ? (BWA_IDX_BWT | BWA_IDX_BNS) : BWA_IDX_BWT);
 	if (!idx) { fprintf(stderr, "cannot load index %s\n", argv[1]); return 1; }
 	const bwt_t *bwt = idx->bwt;
 
@@ -365,6 +384,79 @@ int main(int argc, char **argv)
 		fwrite(cseeds.data(), sizeof(seed_out_t), cseeds.size(), fc);
 		fclose(fc);
 		fprintf(stderr, "[ref_dump] chains=%zu chained seeds=%zu\n", chains.size(), cseeds.size());
+	}
+	if (aln_fn) { // the reference's own mem_chain -> mem_chain_flt -> mem_flt_chained_seeds -> mem_chain2aln_across_reads_V2 (comp_seed.cpp:2361-2374),
+		// BATCH_SIZE reads per call as seed_and_extend hands them over.  Dumped: the chains that go INTO the extension driver (after both filters)
+		// and every alignment region it leaves in av_v, purged ones (qb = qe = -1) included.
+		// file: "CSALN01\0"; u64 n_reads, n_chains, n_cseeds, n_regs; u64 chain_off[n+1]; {i64 pos; i32 rid, n; f32 frac_rep; i32 is_alt} chains[];
+		//       {i64 rbeg; i32 qbeg, len, score, pad} cseeds[]; u64 reg_off[n+1];
+		//       {i64 rb, re; i32 qb, qe, rid, score, truesc, w, seedcov, seedlen0; f32 frac_rep; i32 chain} regs[]
+		struct chain_out_t { int64_t pos; int32_t rid, n; float frac_rep; int32_t is_alt; };
+		struct cseed_out_t { int64_t rbeg; int32_t qbeg, len, score, pad; };
+		struct reg_out_t { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0; float frac_rep; int32_t chain; };
+		std::vector<uint64_t> chain_off(n + 1, 0), reg_off(n + 1, 0);
+		std::vector<chain_out_t> chains; std::vector<cseed_out_t> cseeds; std::vector<reg_out_t> regs;
+		mem_cache *mmc = (mem_cache *)calloc(1, sizeof(mem_cache));
+		const int64_t wsize = (int64_t)BATCH_SIZE * SEEDS_PER_READ;
+		mmc->seqBufLeftRef[0] = (uint8_t *)_mm_malloc(wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64); mmc->seqBufRightRef[0] = (uint8_t *)_mm_malloc(wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64);
+		mmc->seqBufLeftQer[0] = (uint8_t *)_mm_malloc(wsize * MAX_SEQ_LEN_QER + MAX_LINE_LEN, 64); mmc->seqBufRightQer[0] = (uint8_t *)_mm_malloc(wsize * MAX_SEQ_LEN_QER + MAX_LINE_LEN, 64);
+		mmc->wsize_buf_ref[0] = wsize * MAX_SEQ_LEN_REF; mmc->wsize_buf_qer[0] = wsize * MAX_SEQ_LEN_QER;
+		mmc->seqPairArrayAux[0] = (SeqPair *)malloc((wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+		mmc->seqPairArrayLeft128[0] = (SeqPair *)malloc((wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+		mmc->seqPairArrayRight128[0] = (SeqPair *)malloc((wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+		mmc->wsize[0] = wsize;
+		mmc->lim[0] = (int32_t *)_mm_malloc((BATCH_SIZE + 32) * sizeof(int32_t), 64);
+		for (size_t b0 = 0; b0 < n; b0 += BATCH_SIZE) {
+			const int nb = (int)std::min<size_t>(BATCH_SIZE, n - b0);
+			std::vector<std::vector<uint8_t>> codes((size_t)nb);
+			std::vector<bseq1_t> sq((size_t)nb);
+			std::vector<mem_chain_v> chain_ar((size_t)nb); std::vector<mem_alnreg_v> reg_ar((size_t)nb);
+			for (int r = 0; r < nb; r++) {
+				const std::string &rd = reads[b0 + r];
+				codes[r].assign(rd.size() + 1, 4);
+				for (size_t j = 0; j < rd.size(); j++) codes[r][j] = nst_nt4_table[(uint8_t)rd[j]];
+				memset(&sq[r], 0, sizeof(bseq1_t)); sq[r].l_seq = (int)rd.size(); sq[r].seq = (char *)codes[r].data();
+				std::vector<bwtintv_t> match(mems.begin() + mem_off[b0 + r], mems.begin() + mem_off[b0 + r + 1]);
+				std::vector<mem_seed_t> sd;
+				for (uint64_t i = seed_off[b0 + r]; i < seed_off[b0 + r + 1]; i++) {
+					mem_seed_t s; memset(&s, 0, sizeof s);
+					s.rbeg = seeds[i].rbeg; s.qbeg = seeds[i].qbeg; s.len = s.score = seeds[i].len;
+					sd.push_back(s);
+				}
+				mem_chain_v chn = mem_chain(opt, idx->bns, sq[r].l_seq, match, sd);
+				chn.n = mem_chain_flt(opt, chn.n, chn.a);
+				mem_flt_chained_seeds(opt, idx->bns, idx->pac, sq[r].l_seq, codes[r].data(), chn.n, chn.a);
+				chain_ar[r] = chn;
+				kv_init(reg_ar[r]);
+				for (size_t c = 0; c < chn.n; c++) {
+					chain_out_t o = {chn.a[c].pos, chn.a[c].rid, chn.a[c].n, chn.a[c].frac_rep, (int32_t)chn.a[c].is_alt};
+					chains.push_back(o);
+					for (int j = 0; j < chn.a[c].n; j++) { const mem_seed_t &t = chn.a[c].seeds[j]; cseed_out_t s = {t.rbeg, t.qbeg, t.len, t.score, 0}; cseeds.push_back(s); }
+				}
+				chain_off[b0 + r + 1] = chains.size();
+			}
+			mem_chain2aln_across_reads_V2(opt, idx->bns, idx->pac, sq.data(), nb, chain_ar.data(), reg_ar.data(), mmc, 0);
+			for (int r = 0; r < nb; r++) {
+				for (size_t i = 0; i < reg_ar[r].n; i++) {
+					const mem_alnreg_t &a = reg_ar[r].a[i];
+					reg_out_t o = {a.rb, a.re, a.qb, a.qe, a.rid, a.score, a.truesc, a.w, a.seedcov, a.seedlen0, a.frac_rep, (int32_t)(a.c - chain_ar[r].a)};
+					regs.push_back(o);
+				}
+				reg_off[b0 + r + 1] = regs.size();
+				for (size_t c = 0; c < chain_ar[r].n; c++) free(chain_ar[r].a[c].seeds);
+				free(chain_ar[r].a); free(reg_ar[r].a);
+			}
+		}
+		FILE *fa = fopen(aln_fn, "wb");
+		if (!fa) { perror(aln_fn); return 1; }
+		uint64_t h4[4] = {n, chains.size(), cseeds.size(), regs.size()};
+		fwrite("CSALN01", 1, 8, fa); fwrite(h4, 8, 4, fa);
+		fwrite(chain_off.data(), 8, n + 1, fa); fwrite(chains.data(), sizeof(chain_out_t), chains.size(), fa); fwrite(cseeds.data(), sizeof(cseed_out_t), cseeds.size(), fa);
+		fwrite(reg_off.data(), 8, n + 1, fa); fwrite(regs.data(), sizeof(reg_out_t), regs.size(), fa);
+		fclose(fa);
+		size_t purged = 0;
+		for (const auto &g : regs) purged += g.qb == -1 && g.qe == -1;
+		fprintf(stderr, "[ref_dump] extension: chains=%zu seeds=%zu regions=%zu (purged %zu)\n", chains.size(), cseeds.size(), regs.size(), purged);
 	}
 	return n_diff ? 2 : 0;
 }

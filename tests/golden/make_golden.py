@@ -15,6 +15,7 @@ What is produced (all data, no reference source text):
   MANIFEST.json                      md5 of every file + the harness stderr summary per run
   bsw1/                              `make_golden.py bsw`: every banded-SW extension the reference performed on the read sets (inputs + 6 outputs),
                                      recorded from its own run, and known answers of its scalar ksw_extend2
+  aln1/                              `make_golden.py aln`: the reference's extension stage (mem_chain2aln_across_reads_V2): filtered chains in, alignment regions out
   c2/config2.json                    `make_golden.py bigref`: md5 of bwaidx's five files for a 64 Mbp genome (its bwt_bwtgen2 branch)
   alt1/                              `make_golden.py alt`: main100's chains with a <prefix>.alt file naming chr2 (is_alt of the chains)
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
@@ -316,6 +317,52 @@ def make_bigref():
     print(json.dumps(out, indent=1))
 
 
+def parse_aln(path):
+    raw = open(path, "rb").read()
+    assert raw[:7] == b"CSALN01"
+    n, n_chains, n_cseeds, n_regs = [int(x) for x in np.frombuffer(raw, dtype="<u8", count=4, offset=8)]
+    off = 40
+    chain_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
+    ch = np.frombuffer(raw, dtype=np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n", "<i4"), ("frac_rep", "<f4"), ("is_alt", "<i4")]), count=n_chains, offset=off); off += 24 * n_chains
+    sd = np.frombuffer(raw, dtype=np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("pad", "<i4")]), count=n_cseeds, offset=off); off += 24 * n_cseeds
+    reg_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
+    rg = np.frombuffer(raw, dtype=np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4"),
+                                             ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"), ("chain", "<i4")]), count=n_regs, offset=off)
+    out = dict(chain_off=chain_off.copy(), reg_off=reg_off.copy())
+    for k in ch.dtype.names:
+        out["chain_" + k] = ch[k].copy()
+    for k in ("rbeg", "qbeg", "len", "score"):
+        out["cseed_" + k] = sd[k].copy()
+    for k in rg.dtype.names:
+        out["reg_" + k] = rg[k].copy()
+    return out
+
+
+def make_aln():
+    """aln1/: the reference's extension stage as a whole.  oracle/_ref/ref_dump --aln runs, per 512 reads, the reference's own mem_chain ->
+    mem_chain_flt -> mem_flt_chained_seeds -> mem_chain2aln_across_reads_V2 (comp_seed.cpp:2361-2374) and dumps the chains that go INTO the
+    extension driver and every alignment region it leaves (purged ones included): rb re qb qe rid score truesc w seedcov seedlen0 frac_rep
+    and the region's chain.  Read sets: g1's four and the first 400 reads of bsw1/indel150.txt (insertions and deletions)."""
+    import tempfile
+    d = os.path.join(HERE, "aln1"); os.makedirs(d, exist_ok=True)
+    g1 = os.path.join(HERE, "g1")
+    ind = open(os.path.join(HERE, "bsw1", "indel150.txt")).read().split("\n")[:400]
+    open(os.path.join(d, "indel150_400.txt"), "w").write("".join(x + "\n" for x in ind))
+    summary = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, rd_dir in (("main100", g1), ("sorted150", g1), ("ragged", g1), ("repeat100", g1), ("indel150_400", d)):
+            tmp, atmp = os.path.join(td, "o.bin"), os.path.join(td, "a.bin")
+            r = run([os.path.join(REFBIN, "ref_dump"), os.path.join(g1, "ref"), os.path.join(rd_dir, name + ".txt"), tmp, "--aln", atmp])
+            if r.returncode:
+                sys.exit(r.stderr)
+            a = parse_aln(atmp)
+            np.savez_compressed(os.path.join(d, name + ".aln.npz"), **a)
+            summary[name] = r.stderr.strip().splitlines()[-1]
+    summary["md5"] = {fn: md5(os.path.join(d, fn)) for fn in sorted(os.listdir(d)) if fn != "MANIFEST.json"}
+    json.dump(summary, open(os.path.join(d, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
@@ -327,6 +374,8 @@ def main():
         return make_bsw()
     if len(sys.argv) > 1 and sys.argv[1] == "bigref":
         return make_bigref()
+    if len(sys.argv) > 1 and sys.argv[1] == "aln":
+        return make_aln()
     rng = random.Random(20261003)
     d = os.path.join(HERE, "g1")
     os.makedirs(d, exist_ok=True)

@@ -93,7 +93,7 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
     import compseed_amd.binding as b
     structs = {"cs_index_view_t": b.IndexView, "cs_params_t": b.Params, "cs_result_t": b.CResult, "cs_stats_t": b.Stats,
                "cs_engine_options_t": b.EngineOptions, "cs_traffic_t": b.Traffic, "cs_digest_t": b.Digest, "cs_packed_result_t": b.CPacked, "cs_ext_params_t": b.ExtParams, "cs_ext_stats_t": b.ExtStats,
-               "cs_index_check_t": b.IndexCheck}
+               "cs_index_check_t": b.IndexCheck, "cs_aln_params_t": b.AlnParams, "cs_aln_result_t": b.CAlnResult, "cs_aln_stats_t": b.AlnStats}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {']
     for cname, st in structs.items():
         src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -110,7 +110,7 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
         for fname, _ in st._fields_:
             assert int(got["%s.%s" % (cname, fname)]) == getattr(st, fname).offset, (cname, fname)
     # the two array-element structs of the extension entry points are numpy dtypes on the Python side
-    for cname, dt in (("cs_ext_pair_t", b.EXT_PAIR_DT), ("cs_ext_result_t", b.EXT_RES_DT)):
+    for cname, dt in (("cs_ext_pair_t", b.EXT_PAIR_DT), ("cs_ext_result_t", b.EXT_RES_DT), ("cs_alnreg_t", b.ALNREG_DT)):
         src2 = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {', 'printf("%%zu\\n", sizeof(%s));' % cname]
         src2 += ['printf("%%zu\\n", offsetof(%s, %s));' % (cname, f) for f in dt.names] + ["return 0; }"]
         c2 = tmp_path / (cname + ".c"); c2.write_text("\n".join(src2))

@@ -1,0 +1,72 @@
+"""The extension stage as a whole on the GPU box (cs_extend_chains, compseed_amd/csrc/align.cpp + extend.hip) against the REAL reference's
+mem_chain2aln_across_reads_V2 (mapping/comp_seed.cpp:1319-2237): tests/golden/aln1/ holds, for five read sets, the chains the reference fed
+into it (after its own mem_chain_flt / mem_flt_chained_seeds) and every alignment region it left -- rb re qb qe rid score truesc w seedcov
+seedlen0 frac_rep, the region's chain, purged regions (qb = qe = -1) included (oracle/ref_harness.cpp --aln, tests/golden/make_golden.py aln).
+The library must reproduce every field of every region, in the reference's order."""
+import os
+
+import numpy as np
+import pytest
+
+import _data
+
+pytestmark = pytest.mark.gpu
+ALN = os.path.join(os.path.dirname(_data.GOLD), "aln1")
+
+
+def _load(name):
+    z = np.load(os.path.join(ALN, name + ".aln.npz"))
+    rd_dir = ALN if name.startswith("indel") else _data.GOLD
+    raw = open(os.path.join(rd_dir, name + ".txt"), "rb").read()
+    reads = raw.split(b"\n")[:-1] if raw.endswith(b"\n") else raw.split(b"\n")
+    bases, off = _data.pack_reads(reads)
+    return z, bases, off
+
+
+@pytest.mark.parametrize("name", ["main100", "sorted150", "ragged", "repeat100", "indel150_400"])
+def test_alignment_regions_are_the_references(name):
+    import compseed_amd as ca
+    z, bases, off = _load(name)
+    n_chains = z["chain_pos"].size
+    chains = np.zeros(n_chains, dtype=ca.CHAIN_DT)
+    chains["pos"], chains["rid"], chains["n_seeds"], chains["frac_rep"], chains["is_alt"] = z["chain_pos"], z["chain_rid"], z["chain_n"], z["chain_frac_rep"], z["chain_is_alt"]
+    cseed_off = np.zeros(n_chains + 1, dtype=np.uint64); np.cumsum(z["chain_n"].astype(np.uint64), out=cseed_off[1:])
+    cseeds = np.zeros(z["cseed_rbeg"].size, dtype=ca.SEED_DT)
+    cseeds["rbeg"], cseeds["qbeg"], cseeds["len"] = z["cseed_rbeg"], z["cseed_qbeg"], z["cseed_len"]
+    al = ca.Aligner(_data.PREFIX, 0)
+    got = al.extend_chains(z["chain_off"], chains, cseed_off, cseeds, bases, off, cseed_score=z["cseed_score"])
+    st = al.stats()
+    al.close()
+    assert np.array_equal(got["reg_off"], z["reg_off"])
+    g = got["regs"]
+    purged = (z["reg_qb"] == -1) & (z["reg_qe"] == -1)
+    assert np.array_equal((g["qb"] == -1) & (g["qe"] == -1), purged), (name, int(((g["qb"] == -1) & (g["qe"] == -1)).sum()), int(purged.sum()))
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "chain"):
+        assert np.array_equal(g[f], z["reg_" + f]), (name, f, int((g[f] != z["reg_" + f]).sum()))
+    assert np.array_equal(g["frac_rep"].view(np.uint32), z["reg_frac_rep"].view(np.uint32))
+    assert st["regions"] == g.size and st["purged"] == int(purged.sum()) and st["pairs"] >= st["regions"] // 2
+    assert g.size > 4000 and purged.sum() > 1000
+
+
+def test_engine_chainer_aligner_end_to_end():
+    """reads -> GPU seeding -> chains (cs_chain_batch) -> GPU extension, all through the C ABI: the chains are unfiltered here (the reference's
+    chain filters are the caller's), so the regions are compared with what the same driver gives for the golden's own seeds -- and every
+    surviving region must be a consistent local alignment frame (inside the read and the reference, score at least the seed's)"""
+    import compseed_amd as ca
+    bases, off = _data.load_reads("sorted150")
+    ix = ca.Index.load(_data.PREFIX)
+    eng = ca.Engine(ix, 0)
+    res = eng.seed_batch(bases, off, ca.Params())
+    ch = ca.Chainer(_data.PREFIX)
+    c = ch.chain(res.mem_off, res.mems, res.seed_off, res.seeds, off, ca.ChainParams(), threads=2)
+    al = ca.Aligner(_data.PREFIX, 0)
+    got = al.extend_chains(c["chain_off"], c["chains"], c["cseed_off"], c["cseeds"], bases, off)
+    g = got["regs"]
+    assert g.size == c["cseeds"].size
+    live = ~((g["qb"] == -1) & (g["qe"] == -1))
+    read_of = np.repeat(np.arange(off.size - 1), np.diff(got["reg_off"].astype(np.int64)))
+    rl = np.diff(off.astype(np.int64))[read_of]
+    assert (g["qb"][live] >= 0).all() and (g["qe"][live] <= rl[live]).all() and (g["qb"][live] < g["qe"][live]).all()
+    assert (g["rb"][live] >= 0).all() and (g["re"][live] > g["rb"][live]).all() and (g["score"][live] >= g["seedlen0"][live]).all()
+    assert live.sum() > 1000
+    al.close(); ch.close(); eng.close(); ix.close()
