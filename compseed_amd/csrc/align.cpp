@@ -13,7 +13,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct cs_aligner {
@@ -59,6 +61,7 @@ extern "C" void cs_aln_params_default(cs_aln_params_t *p)
 	if (!p) return;
 	// mem_opt_init (comp_seed.cpp:26-58)
 	p->a = 1; p->b = 4; p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1; p->pen_clip5 = p->pen_clip3 = 5; p->w = 100; p->zdrop = 100;
+	p->threads = 8;
 }
 
 extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_params_t *par, cs_aligner_t **out)
@@ -110,87 +113,121 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 	A->reg_off.assign((size_t)n + 1, 0); A->regs.clear();
 	A->regs.reserve((size_t)chains->n_seeds);
 
+	// Host work is per read and independent: T threads take contiguous read ranges; each builds its regions, jobs and target windows into
+	// buffers of its own, which are then joined (region and window offsets shifted by what the ranges before it produced).
+	const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(o.threads > 0 ? o.threads : 1, 64), n / 256 + 1));
+	auto for_ranges = [&](auto &&fn) {
+		std::vector<std::thread> th;
+		for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(t, n * t / T, n * (t + 1) / T); });
+		fn(0, (int64_t)0, n / T);
+		for (auto &x : th) x.join();
+	};
 	// ---- the two sequence buffers.  Queries: every read once as codes and once reversed.  A left extension reads the reversed prefix
 	// [0, qbeg) = a suffix of the reversed read, a right extension the suffix [qe, len) of the forward read (comp_seed.cpp:1525,1665).
 	const uint64_t n_bases = n ? read_offsets[n] : 0;
 	std::vector<uint8_t> qbuf((size_t)n_bases * 2 + 8);
-	for (int64_t r = 0; r < n; ++r) {
-		const uint64_t b0 = read_offsets[r], len = read_offsets[r + 1] - b0;
-		for (uint64_t j = 0; j < len; ++j) { const uint8_t c = base_code(bases[b0 + j]); qbuf[b0 + j] = c; qbuf[n_bases + b0 + (len - 1 - j)] = c; }
-	}
-	// Targets: per chain the reference window [w0, w1) the chain's seeds can reach (comp_seed.cpp:1395-1428), forward and reversed.
-	std::vector<uint8_t> tbuf;
-	std::vector<Job> left, right;
-	struct Meta { int64_t read; const cs_seed_t *seeds; int32_t n_seeds; };   // per region: what the later passes need
-	std::vector<Meta> meta;
-	std::vector<int32_t> h0_left;                                              // h0 of the left jobs (seed length x match)
-	std::vector<std::vector<uint32_t>> order_of_chain((size_t)chains->n_chains); // seeds in the order they were extended (for the purge pass)
-	for (int64_t r = 0; r < n; ++r) {
-		const int l_query = (int)(read_offsets[r + 1] - read_offsets[r]);
-		for (uint64_t ci = chains->chain_off[r]; ci < chains->chain_off[r + 1]; ++ci) {
-			const cs_chain_t &c = chains->chains[ci];
-			const cs_seed_t *sd = chains->cseeds + chains->cseed_off[ci];
-			const int32_t *sc = cseed_score ? cseed_score + chains->cseed_off[ci] : nullptr;
-			const int ns = c.n_seeds;
-			if (ns <= 0) continue;
-			int64_t w0 = l_pac << 1, w1 = 0;
-			for (int i = 0; i < ns; ++i) {
-				const cs_seed_t &t = sd[i];
-				const int64_t b = t.rbeg - (t.qbeg + affordable_gap(o, t.qbeg));
-				const int tail = l_query - t.qbeg - t.len;
-				const int64_t e = t.rbeg + t.len + (tail + affordable_gap(o, tail));
-				w0 = std::min(w0, b); w1 = std::max(w1, e);
-			}
-			w0 = std::max<int64_t>(w0, 0); w1 = std::min<int64_t>(w1, l_pac << 1);
-			if (w0 < l_pac && l_pac < w1) { if (sd[0].rbeg < l_pac) w1 = l_pac; else w0 = l_pac; } // never across the strands
-			{ // clip to the contig of the first seed (bns_fetch_seq, bntseq.c:426-451)
-				const int64_t mid = sd[0].rbeg;
-				const bool rev = mid >= l_pac;
-				const int rid = contig_at(R, rev ? (l_pac << 1) - 1 - mid : mid);
-				if (rid < 0 || !(w0 <= mid && mid < w1)) return cs_fail_(CS_EINVAL, "cs_extend_chains: a chain's first seed lies outside the reference");
-				int64_t far_b = R.offset[(size_t)rid], far_e = far_b + R.len[(size_t)rid];
-				if (rev) { const int64_t t = far_b; far_b = (l_pac << 1) - far_e; far_e = (l_pac << 1) - t; }
-				w0 = std::max(w0, far_b); w1 = std::min(w1, far_e);
-			}
-			const int64_t L = w1 - w0, tb0 = (int64_t)tbuf.size();
-			tbuf.resize(tbuf.size() + (size_t)L * 2);
-			for (int64_t k = 0; k < L; ++k) { // the window's bases: forward strand as stored, reverse strand complemented from the mirror position
-				const int64_t p = w0 + k;
-				const uint8_t b = p < l_pac ? pac_base(A->pac, p) : (uint8_t)(3 - pac_base(A->pac, (l_pac << 1) - 1 - p));
-				tbuf[(size_t)(tb0 + k)] = b; tbuf[(size_t)(tb0 + L + (L - 1 - k))] = b;
-			}
-			// seeds by score, highest first, later ones first among equals (ks_introsort over score << 32 | index, walked from the top: comp_seed.cpp:1440-1458)
-			std::vector<uint32_t> &ord = order_of_chain[(size_t)ci];
-			ord.resize((size_t)ns);
-			for (int i = 0; i < ns; ++i) ord[(size_t)i] = (uint32_t)i;
-			std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-				const int sx = sc ? sc[x] : sd[x].len, sy = sc ? sc[y] : sd[y].len;
-				return sx != sy ? sx > sy : x > y;
-			});
-			const uint64_t rb0 = read_offsets[r];
-			for (int k = 0; k < ns; ++k) {
-				const cs_seed_t &s = sd[ord[(size_t)k]];
-				cs_alnreg_t a; memset(&a, 0, sizeof a);
-				a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = (int32_t)(ci - chains->chain_off[r]);
-				a.rb = a.re = UNSET; a.qb = a.qe = UNSET;
-				const uint32_t reg = (uint32_t)A->regs.size();
-				if (s.qbeg) { // left: reversed read prefix against the reversed window in front of the seed
-					const int64_t tl = s.rbeg - w0;
-					Job j = {reg, (int64_t)(n_bases + rb0 + (uint64_t)(l_query - s.qbeg)), tb0 + L + (L - tl), s.qbeg, (int32_t)tl};
-					left.push_back(j); h0_left.push_back(s.len * o.a);
-					a.qb = s.qbeg; a.rb = s.rbeg;
-				} else { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; }
-				if (s.qbeg + s.len != l_query) { // right: the rest of the read against the window behind the seed
-					const int qe = s.qbeg + s.len; const int64_t re = s.rbeg + s.len - w0;
-					Job j = {reg, (int64_t)(rb0 + (uint64_t)qe), tb0 + re, l_query - qe, (int32_t)(L - re)};
-					right.push_back(j);
-					a.qe = qe; a.re = w0 + re;
-				} else { a.qe = l_query; a.re = s.rbeg + s.len; }
-				A->regs.push_back(a);
-				Meta m = {r, sd, ns}; meta.push_back(m);
-			}
+	for_ranges([&](int, int64_t r0, int64_t r1) {
+		for (int64_t r = r0; r < r1; ++r) {
+			const uint64_t b0 = read_offsets[r], len = read_offsets[r + 1] - b0;
+			for (uint64_t j = 0; j < len; ++j) { const uint8_t c = base_code(bases[b0 + j]); qbuf[b0 + j] = c; qbuf[n_bases + b0 + (len - 1 - j)] = c; }
 		}
-		A->reg_off[(size_t)r + 1] = A->regs.size();
+	});
+	// Targets: per chain the reference window [w0, w1) the chain's seeds can reach (comp_seed.cpp:1395-1428), forward and reversed.
+	struct Meta { int64_t read; const cs_seed_t *seeds; int32_t n_seeds; };   // per region: what the later passes need
+	struct Part { std::vector<cs_alnreg_t> regs; std::vector<Meta> meta; std::vector<Job> left, right; std::vector<int32_t> h0_left; std::vector<uint8_t> tbuf; bool bad = false; };
+	std::vector<Part> part((size_t)T);
+	std::vector<std::vector<uint32_t>> order_of_chain((size_t)chains->n_chains); // seeds in the order they were extended (for the purge pass)
+	for_ranges([&](int t, int64_t r0, int64_t r1) {
+		Part &P = part[(size_t)t];
+		for (int64_t r = r0; r < r1; ++r) {
+			const int l_query = (int)(read_offsets[r + 1] - read_offsets[r]);
+			for (uint64_t ci = chains->chain_off[r]; ci < chains->chain_off[r + 1]; ++ci) {
+				const cs_chain_t &c = chains->chains[ci];
+				const cs_seed_t *sd = chains->cseeds + chains->cseed_off[ci];
+				const int32_t *sc = cseed_score ? cseed_score + chains->cseed_off[ci] : nullptr;
+				const int ns = c.n_seeds;
+				if (ns <= 0) continue;
+				int64_t w0 = l_pac << 1, w1 = 0;
+				for (int i = 0; i < ns; ++i) {
+					const cs_seed_t &sdi = sd[i];
+					const int64_t b = sdi.rbeg - (sdi.qbeg + affordable_gap(o, sdi.qbeg));
+					const int tail = l_query - sdi.qbeg - sdi.len;
+					const int64_t e = sdi.rbeg + sdi.len + (tail + affordable_gap(o, tail));
+					w0 = std::min(w0, b); w1 = std::max(w1, e);
+				}
+				w0 = std::max<int64_t>(w0, 0); w1 = std::min<int64_t>(w1, l_pac << 1);
+				if (w0 < l_pac && l_pac < w1) { if (sd[0].rbeg < l_pac) w1 = l_pac; else w0 = l_pac; } // never across the strands
+				{ // clip to the contig of the first seed (bns_fetch_seq, bntseq.c:426-451)
+					const int64_t mid = sd[0].rbeg;
+					const bool rev = mid >= l_pac;
+					const int rid = contig_at(R, rev ? (l_pac << 1) - 1 - mid : mid);
+					if (rid < 0 || !(w0 <= mid && mid < w1)) { P.bad = true; return; }
+					int64_t far_b = R.offset[(size_t)rid], far_e = far_b + R.len[(size_t)rid];
+					if (rev) { const int64_t x = far_b; far_b = (l_pac << 1) - far_e; far_e = (l_pac << 1) - x; }
+					w0 = std::max(w0, far_b); w1 = std::min(w1, far_e);
+				}
+				const int64_t L = w1 - w0, tb0 = (int64_t)P.tbuf.size();
+				P.tbuf.resize(P.tbuf.size() + (size_t)L * 2);
+				for (int64_t k = 0; k < L; ++k) { // the window's bases: forward strand as stored, reverse strand complemented from the mirror position
+					const int64_t p = w0 + k;
+					const uint8_t b = p < l_pac ? pac_base(A->pac, p) : (uint8_t)(3 - pac_base(A->pac, (l_pac << 1) - 1 - p));
+					P.tbuf[(size_t)(tb0 + k)] = b; P.tbuf[(size_t)(tb0 + L + (L - 1 - k))] = b;
+				}
+				// seeds by score, highest first, later ones first among equals (ks_introsort over score << 32 | index, walked from the top: comp_seed.cpp:1440-1458)
+				std::vector<uint32_t> &ord = order_of_chain[(size_t)ci];
+				ord.resize((size_t)ns);
+				for (int i = 0; i < ns; ++i) ord[(size_t)i] = (uint32_t)i;
+				std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+					const int sx = sc ? sc[x] : sd[x].len, sy = sc ? sc[y] : sd[y].len;
+					return sx != sy ? sx > sy : x > y;
+				});
+				const uint64_t rb0 = read_offsets[r];
+				for (int k = 0; k < ns; ++k) {
+					const cs_seed_t &s = sd[ord[(size_t)k]];
+					cs_alnreg_t a; memset(&a, 0, sizeof a);
+					a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = (int32_t)(ci - chains->chain_off[r]);
+					a.rb = a.re = UNSET; a.qb = a.qe = UNSET;
+					const uint32_t reg = (uint32_t)P.regs.size();                   // (local: shifted when the ranges are joined)
+					if (s.qbeg) { // left: reversed read prefix against the reversed window in front of the seed
+						const int64_t tl = s.rbeg - w0;
+						Job j = {reg, (int64_t)(n_bases + rb0 + (uint64_t)(l_query - s.qbeg)), tb0 + L + (L - tl), s.qbeg, (int32_t)tl};
+						P.left.push_back(j); P.h0_left.push_back(s.len * o.a);
+						a.qb = s.qbeg; a.rb = s.rbeg;
+					} else { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; }
+					if (s.qbeg + s.len != l_query) { // right: the rest of the read against the window behind the seed
+						const int qe = s.qbeg + s.len; const int64_t re = s.rbeg + s.len - w0;
+						Job j = {reg, (int64_t)(rb0 + (uint64_t)qe), tb0 + re, l_query - qe, (int32_t)(L - re)};
+						P.right.push_back(j);
+						a.qe = qe; a.re = w0 + re;
+					} else { a.qe = l_query; a.re = s.rbeg + s.len; }
+					P.regs.push_back(a);
+					Meta m = {r, sd, ns}; P.meta.push_back(m);
+				}
+			}
+			A->reg_off[(size_t)r + 1] = P.regs.size();                                  // (local count so far; made global below)
+		}
+	});
+	for (const Part &P : part) if (P.bad) return cs_fail_(CS_EINVAL, "cs_extend_chains: a chain's first seed lies outside the reference");
+	// join the ranges
+	std::vector<uint8_t> tbuf; std::vector<Job> left, right; std::vector<Meta> meta; std::vector<int32_t> h0_left;
+	{
+		size_t nr = 0, nt = 0, nl = 0, nrt = 0;
+		for (const Part &P : part) { nr += P.regs.size(); nt += P.tbuf.size(); nl += P.left.size(); nrt += P.right.size(); }
+		if (nr >= 0xffffffffull) return cs_fail_(CS_ERANGE, "cs_extend_chains: more than 2^32 regions in one call");
+		A->regs.reserve(nr); meta.reserve(nr); tbuf.resize(nt); left.reserve(nl); right.reserve(nrt); h0_left.reserve(nl);
+		size_t reg_base = 0, t_base = 0;
+		for (int t = 0; t < T; ++t) {
+			Part &P = part[(size_t)t];
+			for (int64_t r = n * t / T; r < n * (t + 1) / T; ++r) A->reg_off[(size_t)r + 1] += reg_base;
+			if (!P.tbuf.empty()) memcpy(tbuf.data() + t_base, P.tbuf.data(), P.tbuf.size());
+			for (Job j : P.left) { j.reg += (uint32_t)reg_base; j.t_off += (int64_t)t_base; left.push_back(j); }
+			for (Job j : P.right) { j.reg += (uint32_t)reg_base; j.t_off += (int64_t)t_base; right.push_back(j); }
+			h0_left.insert(h0_left.end(), P.h0_left.begin(), P.h0_left.end());
+			A->regs.insert(A->regs.end(), P.regs.begin(), P.regs.end());
+			meta.insert(meta.end(), P.meta.begin(), P.meta.end());
+			reg_base += P.regs.size(); t_base += P.tbuf.size();
+			P = Part();
+		}
 	}
 
 	// ---- the dynamic programming, on the GPU: sequences go up once, each band try moves its pairs and results only
@@ -236,20 +273,25 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 	if (rc != CS_OK) return rc;
 
 	// ---- seed coverage of the final region: the chain's seeds that lie inside it on both axes (comp_seed.cpp:1758-1766)
-	for (size_t g = 0; g < A->regs.size(); ++g) {
-		cs_alnreg_t &a = A->regs[g];
-		int cov = 0;
-		for (int i = 0; i < meta[g].n_seeds; ++i) {
-			const cs_seed_t &t = meta[g].seeds[i];
-			if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+	for_ranges([&](int, int64_t r0, int64_t r1) {
+		for (size_t g = (size_t)A->reg_off[(size_t)r0]; g < (size_t)A->reg_off[(size_t)r1]; ++g) {
+			cs_alnreg_t &a = A->regs[g];
+			int cov = 0;
+			for (int i = 0; i < meta[g].n_seeds; ++i) {
+				const cs_seed_t &t = meta[g].seeds[i];
+				if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+			}
+			a.seedcov = cov;
 		}
-		a.seedcov = cov;
-	}
+	});
 
 	// ---- purge (comp_seed.cpp:2141-2232): walking the seeds in the order they were extended, a seed that lies inside an earlier, surviving
 	// region of its read, is not much longer than that region's seed, and sits within the band of its diagonal at either end is redundant
 	// -- unless a later-ranked seed of its chain overlaps it on another diagonal.  Its region is marked qb = qe = -1.
-	for (int64_t r = 0; r < n; ++r) {
+	std::atomic<uint64_t> n_purged(0);
+	for_ranges([&](int, int64_t r0, int64_t r1) {
+	uint64_t my_purged = 0;
+	for (int64_t r = r0; r < r1; ++r) {
 		const int l_query = (int)(read_offsets[r + 1] - read_offsets[r]);
 		const size_t g0 = (size_t)A->reg_off[(size_t)r], g1 = (size_t)A->reg_off[(size_t)r + 1];
 		size_t g = g0; int kept = 0;
@@ -283,12 +325,15 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 						if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) rival = true;
 						else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) rival = true;
 					}
-					if (!rival) { A->regs[g].qb = A->regs[g].qe = -1; ord[(size_t)k] = 0xffffffffu; A->st.purged++; continue; }
+					if (!rival) { A->regs[g].qb = A->regs[g].qe = -1; ord[(size_t)k] = 0xffffffffu; ++my_purged; continue; }
 				}
 				++kept;
 			}
 		}
 	}
+	n_purged += my_purged;
+	});
+	A->st.purged += n_purged.load();
 	A->st.reads += (uint64_t)n; A->st.regions += A->regs.size();
 	out->n_reads = n; out->n_regs = A->regs.size(); out->reg_off = A->reg_off.data(); out->regs = A->regs.data();
 	return CS_OK;
