@@ -118,15 +118,15 @@ EXT_RES_DT = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle"
 class ExtParams(C.Structure):
     """cs_ext_params_t: the arguments of the reference's BandedPairWiseSW constructor (mapping/bandedSWA.h:117-121)"""
     _fields_ = [("mat", C.c_int8 * 25), ("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32), ("e_ins", C.c_int32),
-                ("zdrop", C.c_int32), ("end_bonus", C.c_int32)]
+                ("zdrop", C.c_int32), ("end_bonus", C.c_int32), ("flags", C.c_uint32)]
 
-    def __init__(self, mat=None, o_del=6, e_del=1, o_ins=6, e_ins=1, zdrop=100, end_bonus=5, a=1, b=4):
+    def __init__(self, mat=None, o_del=6, e_del=1, o_ins=6, e_ins=1, zdrop=100, end_bonus=5, a=1, b=4, flags=0):
         super().__init__()
         if mat is None:  # bwa_fill_scmat (bwalib/bwa.c:17-29)
             mat = [(-1 if (i == 4 or j == 4) else a if i == j else -b) for i in range(5) for j in range(5)]
         for i in range(25):
             self.mat[i] = int(mat[i])
-        self.o_del, self.e_del, self.o_ins, self.e_ins, self.zdrop, self.end_bonus = o_del, e_del, o_ins, e_ins, zdrop, end_bonus
+        self.o_del, self.e_del, self.o_ins, self.e_ins, self.zdrop, self.end_bonus, self.flags = o_del, e_del, o_ins, e_ins, zdrop, end_bonus, flags
 
 
 ALNREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4"),

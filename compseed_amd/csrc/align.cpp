@@ -85,7 +85,7 @@ extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_pa
 	}
 	cs_ext_params_t xp;
 	for (int i = 0, k = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) xp.mat[k++] = (int8_t)(i == 4 || j == 4 ? -1 : i == j ? o.a : -o.b); // bwa_fill_scmat (bwalib/bwa.c:17-29)
-	xp.o_del = o.o_del; xp.e_del = o.e_del; xp.o_ins = o.o_ins; xp.e_ins = o.e_ins; xp.zdrop = o.zdrop; xp.end_bonus = o.pen_clip5;
+	xp.o_del = o.o_del; xp.e_del = o.e_del; xp.o_ins = o.o_ins; xp.e_ins = o.e_ins; xp.zdrop = o.zdrop; xp.end_bonus = o.pen_clip5; xp.flags = 0;
 	// (the end bonus only enters the band limit, ksw.c:402-410; the reference builds one object per side, with pen_clip5 and pen_clip3,
 	// comp_seed.cpp:1702-1708: two extenders are kept when the two differ)
 	rc = cs_extender_create(device, &xp, &A->ext);

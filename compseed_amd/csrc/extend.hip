@@ -40,6 +40,7 @@
 namespace cse {
 
 constexpr int NEG = -0x40000000; // identity of max for scores (|score| < 2^30: checked on the host)
+constexpr int DECLINED = (int)0x80000000; // result.score written by extend16_kernel for a pair it leaves to extend_kernel
 
 // ---- cross-lane primitives (gfx9 DPP: row shifts inside the four rows of 16 lanes, then row broadcasts to combine the rows)
 template <int CTRL, int ROW_MASK>
@@ -69,6 +70,7 @@ struct ExtArgs {
 	const uint8_t *qbuf, *tbuf; uint64_t q_bytes, t_bytes;
 	cs_ext_result_t *out;
 	int32_t w, max_qlen;
+	int32_t packed16;                  // extend16_kernel takes the pairs of the 16-bit class; extend_kernel skips what that one has done
 	ExtParams P;
 	const int8_t *mat;                 // the 5 x 5 matrix in device memory (read by the scalar rule only)
 	int32_t *scratch;                  // HBM variant: (max_qlen + 2) x 2 ints per wave
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256, 8) void extend_kernel(const ExtArgs A)
 		}
 		const uint8_t *qg = A.qbuf + pr.q_off, *tg = A.tbuf + pr.t_off;
 		const bool vec_rule = qlen < 32768 && tlen < 32768 && h0 + (qlen < tlen ? qlen : tlen) * P.match < 32768;
+		if (A.packed16 && A.out[p].score != DECLINED) continue;   // extend16_kernel ran first and took this pair
 		// ---- row "-1" (ksw.c:398-400): the seed's score decays along the query by one insertion; both arrays cleared
 		const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
 		for (int j = lane; j <= qlen + 1; j += 64) {
@@ -195,6 +198,167 @@ __global__ __launch_bounds__(256, 8) void extend_kernel(const ExtArgs A)
 	if (lane == 0 && A.stat) { atomicAdd(A.stat, my_cells); atomicAdd(A.stat + 1, my_rows); }
 }
 
+// ---- the same algorithm with TWO query columns per lane, scores as packed int16 (v_pk_add_i16 / v_pk_max_i16 / v_pk_mad_i16).
+// Exact for the pairs whose scores fit: the reference's own 16-bit class, h0 + min(qlen, tlen) x match < 32768 (comp_seed.cpp:1572), with
+// codes below 8 on both sides; everything else is left to extend_kernel (result.score = DECLINED).  A 150-bp read's extension is one chunk
+// of 128 columns per row.  What is packed: M, E, H, the new E, the shift of H by one COLUMN (the previous lane's high half and this lane's
+// low half: one DPP move + v_alignbit), and the scoring -- the query is kept as one 16-bit word per column, bit 2t = "matches target
+// code t", bit 2t+1 = "ambiguous against t", so a row's scores for both columns are one packed shift, two masks and two v_pk_mad_i16.
+// What is not: the max-scan for F runs on one 32-bit value per lane (the larger of its two columns' g + column x e_ins), the row maximum
+// on keys (h << 16 | column), so that the last column of the maximum falls out of the same reduction.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s(uint32_t x) { return __builtin_bit_cast(s16x2, x); }
+__device__ __forceinline__ u16x2 as_us(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ uint32_t as_u(s16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t as_u(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ s16x2 splat(int v) { s16x2 r = {(short)v, (short)v}; return r; }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // v_bfi_b32
+
+__global__ __launch_bounds__(256, 8) void extend16_kernel(const ExtArgs A)
+{
+	extern __shared__ int32_t smem[];
+	const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
+	const int64_t wave = (int64_t)blockIdx.x * wpb + wv, n_waves = (int64_t)gridDim.x * wpb;
+	const int W = (A.max_qlen + 4) >> 1;                               // 32-bit words per array: columns 0 .. max_qlen + 1 and a spare
+	uint32_t *Hw = reinterpret_cast<uint32_t *>(smem) + (size_t)wv * 3 * W, *Ew = Hw + W, *Qw = Ew + W;
+	const ExtParams &P = A.P;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_ins = P.e_ins, e_del = P.e_del;
+	const s16x2 k_oe_ins = splat(oe_ins), k_oe_del = splat(oe_del), k_e_del = splat(e_del), k_zero = splat(0);
+	const s16x2 k_mm = splat(P.mismatch), k_m_minus_mm = splat(P.match - P.mismatch), k_amb_minus_mm = splat(-1 - P.mismatch);
+	const int c0e = 2 * lane * e_ins;                                  // column (relative to the chunk) x e_ins of this lane's low column
+	unsigned long long my_cells = 0, my_rows = 0;
+	for (int64_t p = wave; p < A.n; p += n_waves) { // wave-uniform
+		const cs_ext_pair_t pr = A.pairs[p];
+		const int qlen = pr.qlen, tlen = pr.tlen, h0 = pr.h0;
+		if (qlen < 1 || tlen < 0 || qlen > A.max_qlen || pr.q_off > A.q_bytes || (uint64_t)qlen > A.q_bytes - pr.q_off || pr.t_off > A.t_bytes ||
+		    (uint64_t)tlen > A.t_bytes - pr.t_off || h0 < 0 || !(qlen < 32768 && tlen < 32768 && h0 + (qlen < tlen ? qlen : tlen) * P.match < 32768)) {
+			if (lane == 0) { cs_ext_result_t z = {DECLINED, 0, 0, 0, 0, 0}; A.out[p] = z; }   // (bad pairs are reported by extend_kernel)
+			continue;
+		}
+		const uint8_t *qg = A.qbuf + pr.q_off, *tg = A.tbuf + pr.t_off;
+		// ---- row "-1" and the query's match / ambiguity bits; a code of 8 or more anywhere: not this kernel's pair
+		const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
+		bool odd_code = false;
+		for (int wi = lane; wi < W; wi += 64) {
+			uint32_t hw = 0, qw = 0;
+#pragma unroll
+			for (int hlf = 0; hlf < 2; ++hlf) {
+				const int j = 2 * wi + hlf;
+				const int hv = j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0;
+				uint32_t code = 0;
+				if (j < qlen) {
+					const uint32_t q = qg[j];
+					odd_code |= q > 7u;
+					code = q == 4u ? 0xaaaau : ((q < 8u && q != 4u) ? (1u << (2u * q)) : 0u) | 0x0200u; // ambiguous against everything | matches t == q; target code 4 is ambiguous for every q
+				}
+				hw |= (uint32_t)hv << (16 * hlf); qw |= code << (16 * hlf);
+			}
+			Hw[wi] = hw; Ew[wi] = 0; Qw[wi] = qw;
+		}
+		for (int i = lane; i < tlen; i += 64) odd_code |= tg[i] > 7u;
+		if (__ballot(odd_code)) {
+			if (lane == 0) { cs_ext_result_t z = {DECLINED, 0, 0, 0, 0, 0}; A.out[p] = z; }
+			__builtin_amdgcn_wave_barrier();
+			continue;
+		}
+		int w = A.w;
+		{
+			int lim = (int)((double)(qlen * P.best + P.end_bonus - P.o_ins) / (double)e_ins + 1.);
+			lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+			lim = (int)((double)(qlen * P.best + P.end_bonus - P.o_del) / (double)e_del + 1.);
+			lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+		}
+		__builtin_amdgcn_wave_barrier();
+		int top = h0, top_i = -1, top_j = -1, g_best = -1, g_row = -1, off = 0, beg = 0, end = qlen;
+		int tv = 4;
+		for (int i = 0; i < tlen; ++i) { // wave-uniform
+			if ((i & 63) == 0) tv = i + lane < tlen ? (int)tg[i + lane] : 4;
+			const int ti = __builtin_amdgcn_readlane(tv, i & 63);
+			if (beg < i - w) beg = i - w;
+			if (end > i + w + 1) end = i + w + 1;
+			if (end > qlen) end = qlen;
+			const int left = beg == 0 ? imax(h0 - (P.o_del + e_del * (i + 1)), 0) : 0;
+			int row_max = 0, row_arg = -1, hcarry = left, hlast = left, first_nz = 0x7fffffff, last_nz = -1;
+			int fcarry = (beg & 1) ? e_ins : 0;                       // F(beg) = 0: with an odd beg the chunk starts one (idle) column earlier
+			const u16x2 shift = {(unsigned short)(2 * ti), (unsigned short)(2 * ti)};
+			for (int cb = beg & ~1; cb < end; cb += 128) { // wave-uniform: 128 columns at a time
+				const int j0 = cb + 2 * lane, j1 = j0 + 1;
+				const bool a0 = j0 >= beg && j0 < end, a1 = j1 < end;
+				const uint32_t amask = (a0 ? 0xffffu : 0u) | (a1 ? 0xffff0000u : 0u);
+				int wi = (cb >> 1) + lane; wi = wi < W ? wi : W - 1;
+				const uint32_t hdw = Hw[wi], evw_old = Ew[wi], qcw = Qw[wi];
+				// scores of the two columns against this row's base
+				const u16x2 x = as_us(qcw) >> shift;
+				const s16x2 mb = as_s(as_u(x) & 0x00010001u), ab = as_s((as_u(x) >> 1) & 0x00010001u);
+				const s16x2 sc = mb * k_m_minus_mm + (ab * k_amb_minus_mm + k_mm);
+				// M = Hd ? Hd + S : 0, per half
+				const u16x2 one = {1, 1}, ffff = {0xffff, 0xffff};
+				const uint32_t nzmask = as_u(__builtin_elementwise_min(as_us(hdw), one) * ffff) & amask;
+				const s16x2 Mv = as_s(as_u(as_s(hdw) + sc) & nzmask);
+				const s16x2 gv = pk_max(Mv - k_oe_ins, k_zero);
+				const s16x2 ev = as_s(evw_old & amask);
+				// F: one 32-bit exclusive max-scan per lane over max(g0 + c0 e, g1 + c1 e)
+				const int g0 = a0 ? (int)gv.x : NEG, g1 = a1 ? (int)gv.y : NEG;
+				const int incl = wave_scan_max(imax(g0 + c0e, g1 + c0e + e_ins));
+				const int excl = wave_shift_up(incl, NEG);
+				int F0 = imax(fcarry - c0e, excl - (c0e - e_ins));
+				if (lane == 0) F0 = fcarry;
+				const int F1 = imax(F0 - e_ins, g0);
+				const s16x2 Fv = {(short)F0, (short)F1};
+				uint32_t hw = as_u(pk_max(pk_max(Mv, ev), Fv));
+				if (lane == 0 && !a0) hw = (hw & 0xffff0000u) | (uint32_t)hcarry;   // (odd beg: the idle column in front of the band carries H(i, beg-1))
+				const uint32_t prevw = (uint32_t)wave_shift_up((int)hw, (int)((uint32_t)hcarry << 16));
+				const uint32_t hpw = __builtin_amdgcn_alignbit(hw, prevw, 16);   // low half: the previous column's H, high half: this lane's low column's
+				const uint32_t evn = as_u(pk_max(ev - k_e_del, pk_max(Mv - k_oe_del, k_zero)));
+				if (amask) { Hw[wi] = bfi(amask, hpw, hdw); Ew[wi] = bfi(amask, evn, evw_old); }
+				// row maximum with its LAST column: keys h << 16 | column
+				const int k0 = a0 ? (int)((hw << 16) | (uint32_t)j0) : -1, k1 = a1 ? (int)((hw & 0xffff0000u) | (uint32_t)j1) : -1;
+				const int K = __builtin_amdgcn_readlane(wave_scan_max(imax(k0, k1)), 63);
+				if ((K >> 16) >= row_max) { row_max = K >> 16; row_arg = K & 0xffff; }
+				// live columns for the adaptive band
+				const uint32_t nzw = (hpw | evn) & amask;
+				const unsigned long long nzm = __ballot(nzw != 0);
+				if (nzm) {
+					const int fl = __builtin_ctzll(nzm), ll = 63 - __builtin_clzll(nzm);
+					const uint32_t wf = (uint32_t)__builtin_amdgcn_readlane((int)nzw, fl), wl = (uint32_t)__builtin_amdgcn_readlane((int)nzw, ll);
+					if (first_nz == 0x7fffffff) first_nz = cb + 2 * fl + ((wf & 0xffffu) ? 0 : 1);
+					last_nz = cb + 2 * ll + ((wl >> 16) ? 1 : 0);
+				}
+				const int nact = end - cb < 128 ? end - cb : 128;                 // columns of this chunk inside [.., end)
+				const uint32_t wlast = (uint32_t)__builtin_amdgcn_readlane((int)hw, (nact - 1) >> 1);
+				hlast = ((nact - 1) & 1) ? (int)(wlast >> 16) : (int)(wlast & 0xffffu);
+				hcarry = hlast;
+				fcarry = __builtin_amdgcn_readlane(imax(F1 - e_ins, g1), 63);
+				my_cells += (unsigned)(nact - (cb < beg ? 1 : 0));
+			}
+			if (lane == 0) { reinterpret_cast<uint16_t *>(Hw)[end] = (uint16_t)hlast; reinterpret_cast<uint16_t *>(Ew)[end] = 0; }
+			__builtin_amdgcn_wave_barrier();
+			++my_rows;
+			if ((beg < end ? end : beg) == qlen) {
+				if (!(g_best > hlast)) g_row = i;
+				g_best = imax(g_best, hlast);
+			}
+			if (row_max == 0) break;
+			if (row_max > top) {
+				top = row_max; top_i = i; top_j = row_arg;
+				const int d = row_arg - i; off = imax(off, d < 0 ? -d : d);
+			} else if (P.zdrop > 0) {
+				const int di = i - top_i, dj = row_arg - top_j;
+				if (di > dj) { if (top - row_max - (di - dj) * e_del > P.zdrop) break; }
+				else if (top - row_max - (dj - di) * e_ins > P.zdrop) break;
+			}
+			const int nbeg = first_nz < end ? first_nz : end;
+			const int jz = hlast != 0 ? end : (last_nz >= nbeg ? last_nz : nbeg - 1);
+			beg = nbeg; end = jz + 2 < qlen ? jz + 2 : qlen;
+		}
+		if (lane == 0) { cs_ext_result_t r = {top, top_j + 1, top_i + 1, g_row + 1, g_best, off}; A.out[p] = r; }
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (lane == 0 && A.stat) { atomicAdd(A.stat, my_cells); atomicAdd(A.stat + 1, my_rows); }
+}
+
 __global__ void max_qlen_kernel(const cs_ext_pair_t *pairs, int64_t n, unsigned long long *out)
 {
 	unsigned long long m = 0;
@@ -208,6 +372,7 @@ __global__ void max_qlen_kernel(const cs_ext_pair_t *pairs, int64_t n, unsigned 
 struct cs_extender {
 	int device = 0, n_cu = 256;
 	cse::ExtParams P{};
+	bool packed16 = true;                 // the two-columns-per-lane int16 kernel may be used (parameters fit; not switched off)
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	void *d_pairs = nullptr, *d_q = nullptr, *d_t = nullptr, *d_out = nullptr, *d_scratch = nullptr; size_t c_pairs = 0, c_q = 0, c_t = 0, c_out = 0, c_scratch = 0;
 	uint64_t res_q = 0, res_t = 0;                         // bytes of the sequence buffers uploaded by cs_extender_upload
@@ -231,7 +396,7 @@ extern "C" void cs_ext_params_default(cs_ext_params_t *p)
 	if (!p) return;
 	// mem_opt_init (mapping/comp_seed.cpp:26-58): a = 1, b = 4, o_del = o_ins = 6, e_del = e_ins = 1, zdrop = 100, pen_clip5 = pen_clip3 = 5; bwa_fill_scmat (bwalib/bwa.c:17-29)
 	for (int i = 0, k = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) p->mat[k++] = (int8_t)(i == 4 || j == 4 ? -1 : i == j ? 1 : -4);
-	p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1; p->zdrop = 100; p->end_bonus = 5;
+	p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1; p->zdrop = 100; p->end_bonus = 5; p->flags = 0;
 }
 
 extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_extender_t **out)
@@ -254,6 +419,10 @@ extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_ext
 	x->P.o_del = par->o_del; x->P.e_del = par->e_del; x->P.o_ins = par->o_ins; x->P.e_ins = par->e_ins; x->P.zdrop = par->zdrop; x->P.end_bonus = par->end_bonus;
 	x->P.best = 0;
 	for (int k = 0; k < 25; ++k) x->P.best = std::max<int>(x->P.best, par->mat[k]);
+	// extend16_kernel: int16 arithmetic incl. the F carry's decay over a 128-column chunk, and the vectorised scoring rule written as
+	// mismatch + match-bit x (match - mismatch) + ambiguity-bit x (-1 - mismatch)
+	x->packed16 = !(par->flags & CS_EXT_NO_PACKED16) && par->e_ins <= 200 && par->e_del <= 200 && par->o_ins + par->e_ins < 16000 && par->o_del + par->e_del < 16000 &&
+	              par->mat[0] >= 0 && par->mat[0] <= 100 && par->mat[1] <= 0 && par->mat[1] >= -100;
 	hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&x->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&x->ev1);
@@ -296,6 +465,18 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 	A.P = x->P; A.mat = (const int8_t *)(x->d_ctr + 4); A.scratch = nullptr; A.err = x->d_ctr; A.stat = x->d_ctr + 1;
 	const size_t per_wave = ((size_t)2 * (A.max_qlen + 2) + ((A.max_qlen + 3) >> 2)) * 4; // bytes of LDS per wave
 	HIP_TRYX(hipEventRecord(x->ev0, s));
+	A.packed16 = 0;
+	{ // the pairs of the 16-bit class first, two columns per lane (declines what does not fit: those get DECLINED as their score) ...
+		const size_t per_wave16 = (size_t)3 * ((A.max_qlen + 4) >> 1) * 4;
+		if (x->packed16 && per_wave16 <= 60 * 1024) {
+			const int wpb = per_wave16 <= 15 * 1024 ? 4 : per_wave16 <= 30 * 1024 ? 2 : 1;
+			const int64_t blocks = std::min<int64_t>((n + wpb - 1) / wpb, (int64_t)x->n_cu * (wpb == 4 ? 8 : wpb == 2 ? 4 : 2));
+			hipLaunchKernelGGL(cse::extend16_kernel, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(64 * wpb), per_wave16 * wpb, s, A);
+			HIP_TRYX(hipGetLastError());
+			A.packed16 = 1;
+		}
+	}
+	// ... then everything else (and every pair, where the packed kernel is off) one column per lane
 	if (per_wave <= 60 * 1024) {
 		const int wpb = per_wave <= 15 * 1024 ? 4 : per_wave <= 30 * 1024 ? 2 : 1;
 		const int64_t blocks = std::min<int64_t>((n + wpb - 1) / wpb, (int64_t)x->n_cu * (wpb == 4 ? 8 : wpb == 2 ? 4 : 2));

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 TRACES = ["main100.default", "sorted150.default", "ragged.default", "repeat100.default", "indel150.default", "indel150.scoring2"]
 
 
-def _run_fixture(ca, fx):
+def _run_fixture(ca, fx, flags=0):
     got = np.zeros(fx["meta"].shape[0], dtype=ca.EXT_RES_DT)
     for key, idx in _oracle.bsw_groups(fx["meta"]).items():
         w, zdrop, end_bonus, o_del, e_del, o_ins, e_ins = key
-        x = ca.Extender(0, ca.ExtParams(mat=fx["mat"], o_del=o_del, e_del=e_del, o_ins=o_ins, e_ins=e_ins, zdrop=zdrop, end_bonus=end_bonus))
+        x = ca.Extender(0, ca.ExtParams(mat=fx["mat"], o_del=o_del, e_del=e_del, o_ins=o_ins, e_ins=e_ins, zdrop=zdrop, end_bonus=end_bonus, flags=flags))
         pr = np.zeros(idx.size, dtype=ca.EXT_PAIR_DT)
         for f in ("q_off", "t_off", "qlen", "tlen", "h0"):
             pr[f] = fx["pairs"][f][idx]
@@ -28,11 +28,12 @@ def _run_fixture(ca, fx):
     return got
 
 
+@pytest.mark.parametrize("flags", [0, 1], ids=["packed16+32", "32-bit only"])     # 1 = CS_EXT_NO_PACKED16: both kernels must give the reference's numbers
 @pytest.mark.parametrize("tag", TRACES)
-def test_every_extension_of_the_reference_run(tag):
+def test_every_extension_of_the_reference_run(tag, flags):
     import compseed_amd as ca
     fx = _oracle.bsw_fixture(tag)
-    got = _run_fixture(ca, fx)
+    got = _run_fixture(ca, fx, flags)
     for f in ca.EXT_RES_DT.names:
         assert np.array_equal(got[f], fx["want"][f]), (tag, f, int((got[f] != fx["want"][f]).sum()))
 
@@ -44,9 +45,10 @@ def test_ksw_extend2_known_answers():
     for tag in ("kat_a1b4", "kat_a2b5"):
         fx = _oracle.bsw_fixture(tag)
         assert len(_oracle.bsw_groups(fx["meta"])) <= 160
-        got = _run_fixture(ca, fx)
-        for f in ca.EXT_RES_DT.names:
-            assert np.array_equal(got[f], fx["want"][f]), (tag, f, int((got[f] != fx["want"][f]).sum()))
+        for flags in (0, 1):
+            got = _run_fixture(ca, fx, flags)
+            for f in ca.EXT_RES_DT.names:
+                assert np.array_equal(got[f], fx["want"][f]), (tag, flags, f, int((got[f] != fx["want"][f]).sum()))
 
 
 def _random_pairs(rng, n, qlo, qhi, p_sub=0.03, p_gap=0.01):
@@ -86,15 +88,17 @@ def test_against_the_oracle_on_random_pairs(qlo, qhi, n, par):
         fx = dict(mat=np.array(list(P.mat), dtype=np.int8), pairs=pairs, qbuf=qbuf, tbuf=tbuf,
                   meta=np.tile(np.array([[0, w, P.zdrop, P.end_bonus, P.o_del, P.e_del, P.o_ins, P.e_ins] + [0] * 9], dtype=np.int32), (n, 1)))
         want = _oracle.bsw_extend(fx, threads=8)
-        x = ca.Extender(0, P)
         pr = np.zeros(n, dtype=ca.EXT_PAIR_DT)
         for f in ("q_off", "t_off", "qlen", "tlen", "h0"):
             pr[f] = pairs[f]
-        got = x.extend(pr, qbuf, tbuf, w)
-        st = x.stats()
-        x.close()
-        assert np.array_equal(got, want.astype(ca.EXT_RES_DT)), (qlo, qhi, w, int((got != want.astype(ca.EXT_RES_DT)).sum()))
-        assert st["pairs"] == n and st["cells"] > 0 and st["rows"] > 0
+        for flags in (0, 1):                                 # with and without the two-columns-per-lane int16 kernel
+            P.flags = flags
+            x = ca.Extender(0, P)
+            got = x.extend(pr, qbuf, tbuf, w)
+            st = x.stats()
+            x.close()
+            assert np.array_equal(got, want.astype(ca.EXT_RES_DT)), (qlo, qhi, w, flags, int((got != want.astype(ca.EXT_RES_DT)).sum()))
+            assert st["pairs"] == n and st["cells"] > 0 and st["rows"] > 0
 
 
 def test_device_variant_and_errors():
