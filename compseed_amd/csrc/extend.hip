@@ -70,6 +70,7 @@ struct ExtArgs {
 	const uint8_t *qbuf, *tbuf; uint64_t q_bytes, t_bytes;
 	cs_ext_result_t *out;
 	int32_t w, max_qlen;
+	int32_t min_qlen16;                // extend16_kernel leaves queries of up to this many bases to extend_kernel
 	int32_t packed16;                  // extend16_kernel takes the pairs of the 16-bit class; extend_kernel skips what that one has done
 	ExtParams P;
 	const int8_t *mat;                 // the 5 x 5 matrix in device memory (read by the scalar rule only)
@@ -198,7 +199,13 @@ __global__ __launch_bounds__(256, 8) void extend_kernel(const ExtArgs A)
 	if (lane == 0 && A.stat) { atomicAdd(A.stat, my_cells); atomicAdd(A.stat + 1, my_rows); }
 }
 
-// ---- the same algorithm with TWO query columns per lane, scores as packed int16 (v_pk_add_i16 / v_pk_max_i16 / v_pk_mad_i16).
+// ---- the same algorithm with TWO query columns per lane, scores as packed int16 -- OFF by default (cs_ext_params_t.flags): measured on
+// the bench workload it is exact but not faster (84 ms against 75 ms per 2 M pairs): one 128-column chunk costs 92 VALU instructions
+// against 60 for a 64-column chunk of extend_kernel -- the two max-scans, the ballots and the scalar bookkeeping do not shrink, and
+// unpacking for them eats what the packed element-wise part saves -- and the adaptive band of a 150-bp read's extension rarely needs more
+// than one and a half 64-column chunks per row.  Kept as a second, independently written implementation of the same definition (all
+// fixtures run through both) and as the starting point for longer reads, where rows are several chunks wide.
+// The same algorithm with TWO query columns per lane, scores as packed int16 (v_pk_add_i16 / v_pk_max_i16 / v_pk_mad_i16).
 // Exact for the pairs whose scores fit: the reference's own 16-bit class, h0 + min(qlen, tlen) x match < 32768 (comp_seed.cpp:1572), with
 // codes below 8 on both sides; everything else is left to extend_kernel (result.score = DECLINED).  A 150-bp read's extension is one chunk
 // of 128 columns per row.  What is packed: M, E, H, the new E, the shift of H by one COLUMN (the previous lane's high half and this lane's
@@ -233,7 +240,8 @@ __global__ __launch_bounds__(256, 8) void extend16_kernel(const ExtArgs A)
 		const cs_ext_pair_t pr = A.pairs[p];
 		const int qlen = pr.qlen, tlen = pr.tlen, h0 = pr.h0;
 		if (qlen < 1 || tlen < 0 || qlen > A.max_qlen || pr.q_off > A.q_bytes || (uint64_t)qlen > A.q_bytes - pr.q_off || pr.t_off > A.t_bytes ||
-		    (uint64_t)tlen > A.t_bytes - pr.t_off || h0 < 0 || !(qlen < 32768 && tlen < 32768 && h0 + (qlen < tlen ? qlen : tlen) * P.match < 32768)) {
+		    (uint64_t)tlen > A.t_bytes - pr.t_off || h0 < 0 || !(qlen < 32768 && tlen < 32768 && h0 + (qlen < tlen ? qlen : tlen) * P.match < 32768) ||
+		    qlen <= A.min_qlen16) { // (a query that fits one 64-column chunk is no slower one column per lane: measured)
 			if (lane == 0) { cs_ext_result_t z = {DECLINED, 0, 0, 0, 0, 0}; A.out[p] = z; }   // (bad pairs are reported by extend_kernel)
 			continue;
 		}
@@ -373,6 +381,7 @@ struct cs_extender {
 	int device = 0, n_cu = 256;
 	cse::ExtParams P{};
 	bool packed16 = true;                 // the two-columns-per-lane int16 kernel may be used (parameters fit; not switched off)
+	int min_qlen16 = 64;
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	void *d_pairs = nullptr, *d_q = nullptr, *d_t = nullptr, *d_out = nullptr, *d_scratch = nullptr; size_t c_pairs = 0, c_q = 0, c_t = 0, c_out = 0, c_scratch = 0;
 	uint64_t res_q = 0, res_t = 0;                         // bytes of the sequence buffers uploaded by cs_extender_upload
@@ -421,7 +430,8 @@ extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_ext
 	for (int k = 0; k < 25; ++k) x->P.best = std::max<int>(x->P.best, par->mat[k]);
 	// extend16_kernel: int16 arithmetic incl. the F carry's decay over a 128-column chunk, and the vectorised scoring rule written as
 	// mismatch + match-bit x (match - mismatch) + ambiguity-bit x (-1 - mismatch)
-	x->packed16 = !(par->flags & CS_EXT_NO_PACKED16) && par->e_ins <= 200 && par->e_del <= 200 && par->o_ins + par->e_ins < 16000 && par->o_del + par->e_del < 16000 &&
+	x->min_qlen16 = (par->flags & CS_EXT_PACKED16_ALL) ? 0 : 64;
+	x->packed16 = (par->flags & (CS_EXT_PACKED16 | CS_EXT_PACKED16_ALL)) && par->e_ins <= 200 && par->e_del <= 200 && par->o_ins + par->e_ins < 16000 && par->o_del + par->e_del < 16000 &&
 	              par->mat[0] >= 0 && par->mat[0] <= 100 && par->mat[1] <= 0 && par->mat[1] >= -100;
 	hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&x->ev0);
@@ -465,7 +475,7 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 	A.P = x->P; A.mat = (const int8_t *)(x->d_ctr + 4); A.scratch = nullptr; A.err = x->d_ctr; A.stat = x->d_ctr + 1;
 	const size_t per_wave = ((size_t)2 * (A.max_qlen + 2) + ((A.max_qlen + 3) >> 2)) * 4; // bytes of LDS per wave
 	HIP_TRYX(hipEventRecord(x->ev0, s));
-	A.packed16 = 0;
+	A.packed16 = 0; A.min_qlen16 = x->min_qlen16;
 	{ // the pairs of the 16-bit class first, two columns per lane (declines what does not fit: those get DECLINED as their score) ...
 		const size_t per_wave16 = (size_t)3 * ((A.max_qlen + 4) >> 1) * 4;
 		if (x->packed16 && per_wave16 <= 60 * 1024) {

@@ -299,7 +299,8 @@ int  cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, const cs_resu
  *      memory on the extender's GPU.  Pairs with qlen < 1, tlen < 0 or offsets outside the buffers get a zero result and the call returns
  *      CS_EINVAL after delivering the others. */
 typedef struct { int8_t mat[25]; int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus; uint32_t flags; } cs_ext_params_t;
-#define CS_EXT_NO_PACKED16 1u   /* flags: do not use the two-columns-per-lane int16 kernel (A/B tests; results are identical either way) */
+#define CS_EXT_PACKED16     1u   /* flags: queries longer than 64 bases go through the second kernel (two columns per lane, packed int16); exact, */
+#define CS_EXT_PACKED16_ALL 2u   /* ... all queries of the 16-bit class do.  Default 0: one column per lane for everything (faster on 150-bp reads)    */
 typedef struct { uint64_t q_off, t_off; int32_t qlen, tlen, h0, reserved; } cs_ext_pair_t;
 typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } cs_ext_result_t;
 typedef struct { uint64_t pairs, cells, rows, launches; double kernel_ms; } cs_ext_stats_t;   /* cells = DP cells computed (inside the adaptive band) */

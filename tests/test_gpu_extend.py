@@ -28,7 +28,7 @@ def _run_fixture(ca, fx, flags=0):
     return got
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["packed16+32", "32-bit only"])     # 1 = CS_EXT_NO_PACKED16: both kernels must give the reference's numbers
+@pytest.mark.parametrize("flags", [0, 1, 2], ids=["default", "packed16 above 64 bases", "packed16 for all"])   # CS_EXT_PACKED16 / CS_EXT_PACKED16_ALL: every mix of the two kernels must give the reference's numbers
 @pytest.mark.parametrize("tag", TRACES)
 def test_every_extension_of_the_reference_run(tag, flags):
     import compseed_amd as ca
@@ -45,7 +45,7 @@ def test_ksw_extend2_known_answers():
     for tag in ("kat_a1b4", "kat_a2b5"):
         fx = _oracle.bsw_fixture(tag)
         assert len(_oracle.bsw_groups(fx["meta"])) <= 160
-        for flags in (0, 1):
+        for flags in (0, 1, 2):
             got = _run_fixture(ca, fx, flags)
             for f in ca.EXT_RES_DT.names:
                 assert np.array_equal(got[f], fx["want"][f]), (tag, flags, f, int((got[f] != fx["want"][f]).sum()))
@@ -91,7 +91,7 @@ def test_against_the_oracle_on_random_pairs(qlo, qhi, n, par):
         pr = np.zeros(n, dtype=ca.EXT_PAIR_DT)
         for f in ("q_off", "t_off", "qlen", "tlen", "h0"):
             pr[f] = pairs[f]
-        for flags in (0, 1):                                 # with and without the two-columns-per-lane int16 kernel
+        for flags in (0, 1, 2):                              # one column per lane (default), the int16 kernel for long queries, for all
             P.flags = flags
             x = ca.Extender(0, P)
             got = x.extend(pr, qbuf, tbuf, w)
