@@ -1228,10 +1228,13 @@ static void pipe_upload_thread(cs_engine *e)
 			j.in_slot = hp.in_free[0] ? 0 : 1; hp.in_free[j.in_slot] = 0;
 		}
 		hipError_t he = hipSuccess;
+		const auto tu0 = std::chrono::steady_clock::now();
 		if (j.nb) he = hipMemcpyAsync(e->hp_in[j.in_slot].p, j.bases + j.b0, (size_t)j.nb, hipMemcpyHostToDevice, e->s_up);
 		if (he == hipSuccess && j.offsets) he = hipMemcpyAsync(e->hp_inoff[j.in_slot].p, j.offsets + j.r0, ((size_t)j.n + 1) * 8, hipMemcpyHostToDevice, e->s_up);
 		if (he == hipSuccess && j.offsets) { hipLaunchKernelGGL(rebase_words_kernel, dim3(1), dim3(1024), 0, e->s_up, e->hp_inoff[j.in_slot].p, (uint64_t)j.n + 1); he = hipGetLastError(); }
 		if (he == hipSuccess) he = hipStreamSynchronize(e->s_up);
+		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %.1f MB uploaded in %.1f ms\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (double)j.nb / 1e6,
+		                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
 		std::lock_guard<std::mutex> lk(hp.mu);
 		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch % 3]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
 		hp.q_seed.push_back(j);
@@ -1474,7 +1477,10 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 		hp.cv.wait(lk, [&] { return b.parts_queued == b.parts_total; });
 	}
 	int rc = b.rc; std::string err = b.err;
+	const auto tc0 = std::chrono::steady_clock::now();
 	if (rc == CS_OK && hipEventSynchronize(e->hp_ev_done[rs]) != hipSuccess) { rc = CS_EDEVICE; err = "waiting for the download"; (void)hipGetLastError(); }
+	if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu collected: waited %.1f ms for its download after its last part was queued\n", (unsigned long long)id,
+	                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
 	if (rc == CS_OK && b.expand) {
 		std::unique_lock<std::mutex> lk(hp.mu);
 		hp.cv.wait(lk, [&] { return b.expanded || b.rc != CS_OK; });
