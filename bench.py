@@ -514,7 +514,7 @@ def main():
                 "pipelined_packed_reads_per_s": args.reads / dt_s, "pipelined_packed_ms_per_batch": 1e3 * dt_s,
                 "pageable_input_reads_per_s": args.reads / dt_g,
                 "bit_exact_vs_oracle": bool(ok_x and ok_p), "packed_bytes_per_read": (rp["mems"].nbytes + (rp["seed_rbeg_lo"].nbytes + rp["seed_rbeg_hi"].nbytes if not args.no_sal else 0) + 16 * args.reads) / args.reads,
-                "sub_batch_reads": int(eng.options.pipeline_reads), "expand_threads": int(eng.options.expand_threads),
+                "sub_batch_reads": int(eng.options.pipeline_reads), "expand_threads": int(eng.options.expand_threads), "host_pack_threads": int(eng.options.host_pack_threads),
                 "note": "rank 0, whole call: reads_per_s = cs_engine_seed_batch (reads from pinned host memory in, cs_intv_t / cs_seed_t arrays in host memory "
                         "out: upload, seeding, download and the host-side expansion of the packed results overlapped over sub-batches); packed_reads_per_s = "
                         "cs_engine_seed_batch_packed (the 16-byte / 8-byte form a consumer unpacks while it copies per read anyway); pipelined_packed_reads_per_s "

@@ -14,7 +14,7 @@ SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", 
            "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta", "cs_reader_open", "cs_reader_next", "cs_reader_close",
            "cs_chainer_create", "cs_chainer_destroy", "cs_chain_params_default", "cs_chain_batch",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
-           "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free",
+           "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free", "cs_pack_reads",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync", "cs_packed_seed_rbeg", "cs_engine_check_index",
@@ -60,7 +60,7 @@ class EngineOptions(C.Structure):
                 ("jump_k", C.c_int32), ("kmer_filter", C.c_int32), ("fused", C.c_int32), ("mem_cap", C.c_int32),
                 ("lep_arena_mb", C.c_int64), ("max_raw_mb", C.c_int64), ("r3_text_iter", C.c_int32),
                 ("pipeline_reads", C.c_int32), ("expand_threads", C.c_int32),
-                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("host_pack_threads", C.c_int32), ("reserved", C.c_int32 * 4)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -285,6 +285,7 @@ def load_library():
     L.cs_engine_submit.argtypes = [vp, C.POINTER(Params), i64, vp, u64p]
     L.cs_engine_collect_packed.argtypes = [vp, C.POINTER(CPacked)]
     L.cs_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.cs_pack_reads.argtypes = [vp, vp, C.c_int64, vp, C.c_int, C.c_uint32]
     L.cs_host_free.argtypes = [vp]
     L.cs_engine_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cs_engine_reset_stats.argtypes = [vp]
@@ -535,6 +536,16 @@ def pinned_array(nbytes):
     a = np.frombuffer(buf, dtype=np.uint8).view(PinnedArray)
     a._ptr = p.value
     return a
+
+
+def pack_reads(bases, offsets, threads=1, scalar=False):
+    """cs_pack_reads: the reads as the kernels' 16-byte records of 32 bases -> uint32 array (n_records, 4)"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    rec = np.zeros(((int(offsets[-1]) >> 5) + n, 4), dtype=np.uint32)
+    _check(load_library().cs_pack_reads(bases.ctypes.data, offsets.ctypes.data, n, rec.ctypes.data, int(threads), 1 if scalar else 0))
+    return rec
 
 
 class Engine:

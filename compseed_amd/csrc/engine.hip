@@ -57,7 +57,7 @@ extern "C" void cs_engine_options_default(cs_engine_options_t *o)
 	memset(o, 0, sizeof *o);
 	o->full_sa = 1; o->sa64 = 0; o->text_mode = 1; o->text_arrays = 1; o->jump_k = 15; o->kmer_filter = 1; o->fused = 0;
 	o->mem_cap = 64; o->lep_arena_mb = 32768; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
-	o->pipeline_reads = 5000000; o->expand_threads = 16;
+	o->pipeline_reads = 5000000; o->expand_threads = 16; o->host_pack_threads = 8;
 }
 
 // ------------------------------------------------------------------------------------------------ grow-only buffers
@@ -129,7 +129,7 @@ struct cs_engine {
 	DevBuf<uint8_t> d_pending; // r3text_kernel: reads with calls of rounds 1/2 still queued when it starts
 	DevBuf<uint32_t> d_cnt_snap; DevBuf<uint8_t> d_lcp, d_rep; DevBuf<uint64_t> d_auxA, d_auxB; // re-seeding from the text: capped LCP by row, repeat length by position
 	// inputs
-	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off; DevBuf<uint4> d_seqp; const uint64_t *off_base = nullptr; // d_seqp: pack_reads_kernel's records for the batch whose offsets start at off_base
+	DevBuf<uint8_t> d_raw, d_seq; DevBuf<uint64_t> d_off; DevBuf<uint4> d_seqp; const uint4 *seqp_cur = nullptr; const uint64_t *off_base = nullptr; // d_seqp: pack_reads_kernel's records for the batch whose offsets start at off_base
 	// SMEM stage
 	DevBuf<OutMem> d_out, d_out2; DevBuf<uint32_t> d_cnt, d_cnt2, d_ovf; DevBuf<uint4> d_spill;
 	DevBuf<unsigned long long> d_ctr; // [0] task counter, [1] queries, [2] overflow count, [3] max len
@@ -148,6 +148,7 @@ struct cs_engine {
 	size_t lep_arena_bytes = (size_t)32 << 30;
 	// host variants (seed_host_pipelined): copy streams, two input slots, two pack slots, pinned packed results, expanded results
 	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[3] = {nullptr, nullptr, nullptr};
+	PinBuf<uint4> hp_stage[2]; // records made by the host (host_pack.cpp), staged for the upload into hp_in[slot]
 	DevBuf<uint8_t> hp_in[2], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[2], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<uint32_t> hp_pk_rlo[2]; DevBuf<uint8_t> hp_pk_rhi[2]; // seeds: low words and fifth bytes of rbeg
 	PinBuf<uint64_t> hp_moff[3], hp_soff[3]; PinBuf<uint8_t> hp_mems[3]; PinBuf<uint32_t> hp_rlo[3]; PinBuf<uint8_t> hp_rhi[3]; // three pinned result slots (slot = batch % 3)
 	struct HostPipe *hp = nullptr;
@@ -452,7 +453,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_evc.release(); e->d_sel.release(); e->d_sel_moff.release(); e->d_sel_soff.release(); e->d_sel_mems.release(); e->d_sel_seeds.release();
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
-	for (int k = 0; k < 2; ++k) { e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
+	for (int k = 0; k < 2; ++k) { e->hp_stage[k].release(); e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
 	for (int k = 0; k < 3; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
 	e->x_mems.release(); e->x_seeds.release();
 	for (auto &ev : e->hp_ev_done) if (ev) (void)hipEventDestroy(ev);
@@ -704,7 +705,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 
 	SplitArgs A;
 	A.ix = e->ix; A.seq = e->d_seq.p; A.off = d_off; A.n_reads = nb;
-	A.seqp = e->d_seqp.p + (d_off - e->off_base); // record index = (off[r] >> 5) + r with r counted from the batch's first read
+	A.seqp = e->seqp_cur + (d_off - e->off_base); // record index = (off[r] >> 5) + r with r counted from the batch's first read
 	if (dis & CS_DISABLE_TEXT_MODE) A.ix.text2 = nullptr;
 	A.out = e->d_out.p; A.out_cnt = e->d_cnt.p; A.cap = e->cap;
 	A.ovf = e->d_ovfrec.p; A.ovf_cnt = C + 6; A.ovf_cap = ovf_cap;
@@ -855,8 +856,9 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 
 // ------------------------------------------------------------------------------------------------ the hot path
 static bool pipe_busy(const cs_engine *e);
+// d_recs: the reads as pack_reads_kernel's records when the host made them (d_bases is then null), else null
 static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
-                            uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out)
+                            uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out, const uint4 *d_recs = nullptr)
 {
 	hipStream_t s = e->stream;
 	*n_mems_out = *n_seeds_out = 0;
@@ -880,12 +882,14 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 
 	// The split kernels read the reads as 16-byte records of 32 bases (pack_reads_kernel), made straight from the caller's bytes
 	// (which stay untouched).  The byte-per-base nt4 copy is what the fused kernel reads: made only when that one runs.
-	const bool raw_ok = e->smem_mode == 1 && ((uintptr_t)d_bases & 7u) == 0;
+	if (d_recs && e->smem_mode != 1) return fail(CS_EINVAL, "host-made records need the split kernels");
+	const bool raw_ok = e->smem_mode == 1 && (d_recs || ((uintptr_t)d_bases & 7u) == 0);
 	bool have_nt4 = false;
 	auto make_nt4 = [&]() -> int {
 		if (have_nt4) return CS_OK;
 		CS_TRY(e->d_seq.reserve((size_t)n_bases + 64));
-		if (n_bases) {
+		if (n_bases && d_recs) hipLaunchKernelGGL(unpack_reads_kernel, dim3((unsigned)std::min<int64_t>(grid_for(n_reads * 8, 256), (int64_t)e->n_cu * 16)), dim3(256), 0, s, d_recs, d_off, n_reads, e->d_seq.p);
+		else if (n_bases) {
 			unsigned g = (unsigned)std::min<uint64_t>((n_bases + 255) / 256, (uint64_t)e->n_cu * 16);
 			hipLaunchKernelGGL(nt4_kernel, dim3(g), dim3(256), 0, s, d_bases, e->d_seq.p, n_bases);
 		}
@@ -895,8 +899,10 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	};
 	if (!raw_ok) CS_TRY(make_nt4());
 	const uint64_t n_rec = (n_bases >> 5) + (uint64_t)n_reads;
-	if (e->smem_mode == 1) {
+	if (d_recs) { e->seqp_cur = d_recs; e->off_base = d_off; }
+	else if (e->smem_mode == 1) {
 		CS_TRY(e->d_seqp.reserve((size_t)n_rec + 4));
+		e->seqp_cur = e->d_seqp.p;
 		const dim3 gp((unsigned)std::min<int64_t>(grid_for(n_reads * 8, 256), (int64_t)e->n_cu * 16));
 		if (raw_ok) hipLaunchKernelGGL(pack_reads_kernel<true>, gp, dim3(256), 0, s, d_bases, d_off, n_reads, n_bases, e->d_seqp.p);
 		else hipLaunchKernelGGL(pack_reads_kernel<false>, gp, dim3(256), 0, s, (const uint8_t *)e->d_seq.p, d_off, n_reads, n_bases, e->d_seqp.p);
@@ -904,7 +910,7 @@ static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_read
 	}
 	// byte model, stream part: the bases are read once (twice and written once where the nt4 copy is made), the records written, and
 	// read by the forward, backward and round-3 kernels
-	e->stream_bytes += n_bases * (raw_ok ? 1 : 3) + (e->smem_mode == 1 ? 16 * n_rec * 4 : n_bases * 3);
+	e->stream_bytes += (d_recs ? 0 : n_bases * (raw_ok ? 1 : 3)) + (e->smem_mode == 1 ? 16 * n_rec * (d_recs ? 3 : 4) : n_bases * 3);
 
 	const uint32_t cap = e->cap;
 	int64_t per_launch = (int64_t)std::max<size_t>(1024, e->max_raw_bytes / ((size_t)cap * sizeof(OutMem)));
@@ -1195,7 +1201,7 @@ struct HostJob {
 	uint64_t batch = 0; int part = 0, n_parts = 0;
 	const uint8_t *bases = nullptr; const uint64_t *offsets = nullptr;
 	int64_t r0 = 0, n = 0, n_reads = 0; uint64_t b0 = 0, nb = 0;
-	cs_params_t par{}; bool pk16 = false, expand = false;
+	cs_params_t par{}; bool pk16 = false, expand = false, packed = false; // packed: the host makes the records (host_pack.cpp)
 	int in_slot = 0;
 };
 struct XJob { uint64_t batch; int64_t r0, n; uint64_t mem_base, nm, seed_base, ns; hipEvent_t ev; bool last; };
@@ -1229,11 +1235,21 @@ static void pipe_upload_thread(cs_engine *e)
 		}
 		hipError_t he = hipSuccess;
 		const auto tu0 = std::chrono::steady_clock::now();
-		if (j.nb) he = hipMemcpyAsync(e->hp_in[j.in_slot].p, j.bases + j.b0, (size_t)j.nb, hipMemcpyHostToDevice, e->s_up);
+		if (j.packed) {
+			// the reads as records, made here chunk by chunk: the copy of chunk i runs beside the packing of chunk i + 1
+			uint4 *st = e->hp_stage[j.in_slot].p;
+			const int64_t csz = std::max<int64_t>(262144, (j.n + 7) / 8);
+			for (int64_t c0 = 0; c0 < j.n && he == hipSuccess; c0 += csz) {
+				const int64_t c1 = std::min<int64_t>(j.n, c0 + csz);
+				cs_pack_reads_host_(j.bases, j.offsets, j.r0, j.n, c0, c1, st, e->opt.host_pack_threads, 0);
+				const uint64_t f = ((j.offsets[j.r0 + c0] - j.b0) >> 5) + (uint64_t)c0, l = ((j.offsets[j.r0 + c1] - j.b0) >> 5) + (uint64_t)c1;
+				he = hipMemcpyAsync(e->hp_in[j.in_slot].p + f * 16, st + f, (size_t)(l - f) * 16, hipMemcpyHostToDevice, e->s_up);
+			}
+		} else if (j.nb) he = hipMemcpyAsync(e->hp_in[j.in_slot].p, j.bases + j.b0, (size_t)j.nb, hipMemcpyHostToDevice, e->s_up);
 		if (he == hipSuccess && j.offsets) he = hipMemcpyAsync(e->hp_inoff[j.in_slot].p, j.offsets + j.r0, ((size_t)j.n + 1) * 8, hipMemcpyHostToDevice, e->s_up);
 		if (he == hipSuccess && j.offsets) { hipLaunchKernelGGL(rebase_words_kernel, dim3(1), dim3(1024), 0, e->s_up, e->hp_inoff[j.in_slot].p, (uint64_t)j.n + 1); he = hipGetLastError(); }
 		if (he == hipSuccess) he = hipStreamSynchronize(e->s_up);
-		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %.1f MB uploaded in %.1f ms\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (double)j.nb / 1e6,
+		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %.1f MB %s in %.1f ms\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (double)(j.packed ? ((j.nb >> 5) + (uint64_t)j.n) * 16 : j.nb) / 1e6, j.packed ? "packed on the host and uploaded" : "uploaded",
 		                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
 		std::lock_guard<std::mutex> lk(hp.mu);
 		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch % 3]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
@@ -1297,7 +1313,7 @@ static void pipe_seed_thread(cs_engine *e)
 		const bool sal = j.par.want_sal != 0;
 		const size_t msz = j.pk16 ? 16 : 32;
 		const auto t0 = std::chrono::steady_clock::now();
-		if (rc == CS_OK) { rc = seed_device_impl(e, &j.par, j.n, e->hp_in[j.in_slot].p, e->hp_inoff[j.in_slot].p, j.nb, &nm, &ns); if (rc != CS_OK) err = g_err; }
+		if (rc == CS_OK) { rc = seed_device_impl(e, &j.par, j.n, j.packed ? nullptr : e->hp_in[j.in_slot].p, e->hp_inoff[j.in_slot].p, j.nb, &nm, &ns, j.packed ? reinterpret_cast<const uint4 *>(e->hp_in[j.in_slot].p) : nullptr); if (rc != CS_OK) err = g_err; }
 		if (e->opt.verbose) { // (with the wall clock of the seeding thread: idle gaps between parts show which neighbour it waited for)
 			static const auto t_epoch = std::chrono::steady_clock::now();
 			const auto t1 = std::chrono::steady_clock::now();
@@ -1420,18 +1436,22 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 		cut.push_back(n_reads);
 	}
 	const int64_t kparts = (int64_t)cut.size() - 1;
-	size_t in_cap = 0, off_cap = 0;
+	size_t in_cap = 0, off_cap = 0, stage_cap = 0;
+	const bool host_pack = e->opt.host_pack_threads > 0 && e->smem_mode == 1;
 	for (int64_t i = 0; i < kparts; ++i) {
 		HostJob j; j.batch = id; j.part = (int)i; j.n_parts = (int)kparts; j.bases = bases; j.offsets = offsets; j.n_reads = n_reads;
 		j.r0 = cut[(size_t)i]; j.n = cut[(size_t)i + 1] - j.r0;
 		j.b0 = n_reads ? offsets[j.r0] : 0; j.nb = n_reads ? offsets[j.r0 + j.n] - j.b0 : 0;
 		j.par = *par; j.pk16 = (e->ix.seq_len >> 33) == 0 && max_len < (1u << 15); j.expand = expand;
-		in_cap = std::max<size_t>(in_cap, j.nb); off_cap = std::max<size_t>(off_cap, (size_t)j.n + 1);
+		j.packed = host_pack;
+		const size_t n_rec = (size_t)(j.nb >> 5) + (size_t)j.n;
+		in_cap = std::max<size_t>(in_cap, host_pack ? (n_rec + 4) * 16 : j.nb); off_cap = std::max<size_t>(off_cap, (size_t)j.n + 1);
+		if (host_pack) stage_cap = std::max<size_t>(stage_cap, n_rec + 4);
 		parts.push_back(j);
 	}
 	{ // buffers the threads will use: sized here, while no part of this batch is in flight (earlier batches never need more than they have)
 		std::unique_lock<std::mutex> lk(hp.mu);
-		if (in_cap + 64 > e->hp_in[0].cap || off_cap > e->hp_inoff[0].cap || off_cap > e->hp_pk_moff[0].cap || (par->want_sal && off_cap > e->hp_pk_soff[0].cap)) {
+		if (in_cap + 64 > e->hp_in[0].cap || stage_cap > e->hp_stage[0].cap || off_cap > e->hp_inoff[0].cap || off_cap > e->hp_pk_moff[0].cap || (par->want_sal && off_cap > e->hp_pk_soff[0].cap)) {
 			// a reallocation frees buffers the other batch may still be using: not only while its parts are queued or being seeded
 			// (the input slots are given back right after seed_device_impl), but until the seeding thread has queued the pack kernels
 			// and downloads of its LAST part (parts_queued == parts_total) and those have drained (s_down below)
@@ -1441,7 +1461,7 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 			HIP_TRY(hipStreamSynchronize(e->stream));
 			HIP_TRY(hipStreamSynchronize(e->s_down));
 			for (int k = 0; k < 2; ++k) {
-				CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
+				CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_stage[k].reserve(stage_cap)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
 				if (par->want_sal) CS_TRY(e->hp_pk_soff[k].reserve(off_cap));
 			}
 			lk.lock();

@@ -242,6 +242,21 @@ __global__ void pack_reads_kernel(const uint8_t *seq, const uint64_t *off, int64
 		}
 	}
 }
+// The way back, for the rare case that the host made the records (host_pack.cpp) and the fused kernel has to step in: a byte per
+// base, codes 0..3, 4 for an ambiguous base.
+__global__ void unpack_reads_kernel(const uint4 *rec, const uint64_t *off, int64_t n_reads, uint8_t *out)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+	for (uint64_t r = gid >> 3; r < (uint64_t)n_reads; r += gstride) {
+		const uint64_t rb = off[r], len = off[r + 1] - rb;
+		const uint4 *rr = rec + (rb >> 5) + r;
+		for (uint64_t k = gid & 7; k * 32 < len; k += 8) {
+			const uint4 v = rr[k];
+			const uint64_t bases = (uint64_t)v.x | (uint64_t)v.y << 32, left = len - k * 32;
+			for (uint32_t j = 0; j < 32u && j < left; ++j) out[rb + k * 32 + j] = (uint8_t)((v.z >> j) & 1u ? 4u : (uint32_t)(bases >> (2 * j)) & 3u);
+		}
+	}
+}
 // reader over those records: any position of the read, one load per record entered
 struct PackedReader {
 	const uint4 *rec; uint64_t bases; uint32_t bad; int wk;

@@ -97,7 +97,9 @@ typedef struct {
 	int32_t count_sal_merged; /* [0] 1: also count the distinct SA slots per 512 reads (cs_stats_t.sal_calls as the reference
 	                           *     counts them, comp_seed.cpp:2327-2345); costs one sort of the slots per call              */
 	int32_t verbose;          /* [0] progress lines on stderr                                                                 */
-	int32_t reserved[5];      /* must be 0 */
+	int32_t host_pack_threads;/* [8] host variants: the reads are turned into the kernels' 16-byte / 32-base records by this many
+	                           *     host threads and cross PCIe as 0.6 bytes per base; 0 = upload the caller's bytes, pack on the GPU */
+	int32_t reserved[4];      /* must be 0 */
 } cs_engine_options_t;
 
 /* CSR result of one batch.  Read r owns mems[mem_off[r] .. mem_off[r+1]) sorted by info (comp_seed.cpp:2301) and
@@ -250,6 +252,12 @@ static inline uint32_t cs_mem_seed_count(const cs_intv_t *m, int32_t max_occ) { 
  * too, through a staging thread) */
 int  cs_host_alloc(size_t bytes, void **ptr);
 int  cs_host_free(void *ptr);
+/* What the host variants upload when cs_engine_options_t.host_pack_threads > 0: the reads as the records the seeding kernels read,
+ * 16 bytes per 32 bases (words 0-1: the bases, 2 bits each, base j in bits 2j..2j+1; word 2: one bit per base that is ambiguous or lies
+ * behind the end of the read; word 3: 0), record k of read r at (offsets[r] >> 5) + r + k, (offsets[n_reads] >> 5) + n_reads records in
+ * all; letters as nst_nt4_table maps them (FM_index/bntseq.c:46-63), codes 0..3 as they are (comp_seed.cpp:2259).  Exported for tests. */
+int  cs_pack_reads(const uint8_t *bases, const uint64_t *offsets, int64_t n_reads, void *records, int threads, uint32_t flags);
+#define CS_PACK_SCALAR 1u         /* do not use the AVX2 / BMI2 code path */
 
 /* ---- reordered-reads ingest: the reader step of the reference's pipeline (input_reorder_reads, main.cpp:36-58; FASTQ when the first
  *      byte is '@', main.cpp:399-406; plain or gzip), cutting chunks as main.cpp:54,437 does (the first even read count that reaches

@@ -467,14 +467,14 @@ def _expand_packed(p):
     return mems, seeds
 
 
-@pytest.mark.parametrize("pipeline_reads", [0, 700, 64])
-def test_packed_and_pipelined_host_variants(pipeline_reads):
+@pytest.mark.parametrize("pipeline_reads,host_pack_threads", [(0, 8), (700, 3), (64, 1), (700, 0)])
+def test_packed_and_pipelined_host_variants(pipeline_reads, host_pack_threads):
     """cs_engine_seed_batch_packed (16-byte mems, seeds as rbeg) and cs_engine_seed_batch (the same, expanded on host threads), cut into
     sub-batches of `pipeline_reads` reads whose upload / seeding / download overlap: every golden run, bit for bit, from pageable and
     from pinned input (cs_host_alloc)"""
     import compseed_amd as ca
     ix = ca.Index.load(_data.PREFIX)
-    e = ca.Engine(ix, 0, pipeline_reads=pipeline_reads, expand_threads=3)
+    e = ca.Engine(ix, 0, pipeline_reads=pipeline_reads, expand_threads=3, host_pack_threads=host_pack_threads)   # (0: the caller's bytes go up and the GPU makes the records)
     for name, pname in _data.golden_runs():
         z, kw = _data.load_golden(name, pname)
         bases, off = _data.load_reads(name)
@@ -492,6 +492,25 @@ def test_packed_and_pipelined_host_variants(pipeline_reads):
         r0 = e.seed_batch(bases, off, ca.Params(want_sal=0, **kw))
         assert r0.seeds is None and np.array_equal(r0.mems, mems)
     e.close(); ix.close()
+
+
+def test_host_packed_reads_through_the_fused_kernel():
+    """a split width beyond the task field sends a batch to the fused kernel, which reads a byte per base: made back from the records
+    the host uploaded (unpack_reads_kernel); same results as with the caller's bytes uploaded, and as the oracle's"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    bases, off = _data.load_reads("ragged")
+    par = ca.Params(s=20000)
+    res = []
+    for hpt in (4, 0):
+        e = ca.Engine(ix, 0, host_pack_threads=hpt)
+        res.append(e.seed_batch(bases, off, par))
+        e.close()
+    assert np.array_equal(res[0].mems, res[1].mems) and np.array_equal(res[0].seeds, res[1].seeds) and np.array_equal(res[0].mem_off, res[1].mem_off)
+    o = _oracle.OracleIndex(_data.PREFIX)
+    want = o.seed_batch(bases, off, _oracle.make_params(s=20000), mode=0, threads=2)
+    assert np.array_equal(res[0].mems, want["mems"]) and np.array_equal(res[0].seeds, want["seeds"])
+    o.close(); ix.close()
 
 
 def test_packed_falls_back_to_full_records_for_long_reads(eng):
