@@ -14,7 +14,7 @@ SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", 
            "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta", "cs_reader_open", "cs_reader_next", "cs_reader_close",
            "cs_chainer_create", "cs_chainer_destroy", "cs_chain_params_default", "cs_chain_batch",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
-           "cs_engine_seed_batch_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free", "cs_pack_reads",
+           "cs_engine_seed_batch_device", "cs_engine_submit_device", "cs_engine_collect_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free", "cs_pack_reads",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync", "cs_packed_seed_rbeg", "cs_engine_check_index",
@@ -60,7 +60,7 @@ class EngineOptions(C.Structure):
                 ("jump_k", C.c_int32), ("kmer_filter", C.c_int32), ("fused", C.c_int32), ("mem_cap", C.c_int32),
                 ("lep_arena_mb", C.c_int64), ("max_raw_mb", C.c_int64), ("r3_text_iter", C.c_int32),
                 ("pipeline_reads", C.c_int32), ("expand_threads", C.c_int32),
-                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("host_pack_threads", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("count_sal_merged", C.c_int32), ("verbose", C.c_int32), ("host_pack_threads", C.c_int32), ("passes_in_flight", C.c_int32), ("reserved", C.c_int32 * 3)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -278,6 +278,8 @@ def load_library():
     L.cs_engine_destroy.restype = None
     L.cs_engine_seed_batch.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.POINTER(CResult)]
     L.cs_engine_seed_batch_device.argtypes = [vp, C.POINTER(Params), i64, vp, u64p, C.c_uint64, C.POINTER(CResult)]
+    L.cs_engine_submit_device.argtypes = [vp, C.POINTER(Params), i64, vp, vp, C.c_uint64]
+    L.cs_engine_collect_device.argtypes = [vp, C.POINTER(CResult)]
     L.cs_engine_result_digest.argtypes = [vp, C.POINTER(Digest)]
     L.cs_engine_gather_reads.argtypes = [vp, i64, vp, C.POINTER(CResult)]
     L.cs_engine_traffic_model.argtypes = [vp, C.POINTER(Traffic)]
@@ -627,6 +629,19 @@ class Engine:
         _check(self._L.cs_engine_seed_batch_device(self._h, C.byref(params), int(n_reads), C.c_void_p(d_bases), C.c_void_p(d_offsets),
                                                    int(n_bases), C.byref(res)))
         return Result(res, True, bool(params.want_sal))
+
+    def submit_device(self, d_bases, d_offsets, n_reads, n_bases, params=None):
+        """cs_engine_submit_device: queue a device-resident batch (up to two in flight, seeded on alternating pass contexts)"""
+        params = params or Params()
+        self._dev_sal = getattr(self, "_dev_sal", [])
+        _check(self._L.cs_engine_submit_device(self._h, C.byref(params), int(n_reads), C.c_void_p(d_bases), C.c_void_p(d_offsets), int(n_bases)))
+        self._dev_sal.append(bool(params.want_sal))
+
+    def collect_device(self):
+        """cs_engine_collect_device: the oldest submitted device batch, as device pointers (valid until the second submit from now)"""
+        res = CResult()
+        _check(self._L.cs_engine_collect_device(self._h, C.byref(res)))
+        return Result(res, True, self._dev_sal.pop(0))
 
     def result_digest(self):
         """(mem_off, mems, seed_off, seeds) digests of the result of the last seed call, computed on the device"""

@@ -13,6 +13,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <shared_mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,7 +58,7 @@ extern "C" void cs_engine_options_default(cs_engine_options_t *o)
 	memset(o, 0, sizeof *o);
 	o->full_sa = 1; o->sa64 = 0; o->text_mode = 1; o->text_arrays = 1; o->jump_k = 15; o->kmer_filter = 1; o->fused = 0;
 	o->mem_cap = 64; o->lep_arena_mb = 32768; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
-	o->pipeline_reads = 5000000; o->expand_threads = 16; o->host_pack_threads = 8;
+	o->pipeline_reads = 5000000; o->expand_threads = 16; o->host_pack_threads = 8; o->passes_in_flight = 2;
 }
 
 // ------------------------------------------------------------------------------------------------ grow-only buffers
@@ -146,10 +147,10 @@ struct cs_engine {
 	int occ_win = 5; // ... of bwd_win_kernel
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
 	size_t lep_arena_bytes = (size_t)32 << 30;
-	// host variants (seed_host_pipelined): copy streams, two input slots, two pack slots, pinned packed results, expanded results
+	// host variants (seed_host_pipelined): copy streams, three input slots, two pack slots, pinned packed results, expanded results
 	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[3] = {nullptr, nullptr, nullptr};
-	PinBuf<uint4> hp_stage[2]; // records made by the host (host_pack.cpp), staged for the upload into hp_in[slot]
-	DevBuf<uint8_t> hp_in[2], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[2], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<uint32_t> hp_pk_rlo[2]; DevBuf<uint8_t> hp_pk_rhi[2]; // seeds: low words and fifth bytes of rbeg
+	PinBuf<uint4> hp_stage[3]; // records made by the host (host_pack.cpp), staged for the upload into hp_in[slot]
+	DevBuf<uint8_t> hp_in[3], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[3], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<uint32_t> hp_pk_rlo[2]; DevBuf<uint8_t> hp_pk_rhi[2]; // seeds: low words and fifth bytes of rbeg
 	PinBuf<uint64_t> hp_moff[3], hp_soff[3]; PinBuf<uint8_t> hp_mems[3]; PinBuf<uint32_t> hp_rlo[3]; PinBuf<uint8_t> hp_rhi[3]; // three pinned result slots (slot = batch % 3)
 	struct HostPipe *hp = nullptr;
 	HostBuf<cs_intv_t> x_mems; HostBuf<cs_seed_t> x_seeds;
@@ -160,6 +161,16 @@ struct cs_engine {
 	uint32_t cap = 64;          // mems per read kept by the first pass
 	size_t max_raw_bytes = (size_t)24 << 30;
 	int blocks_per_cu = 2;
+	// Two seeding passes in flight.  The tail of a pass (late iterations with a few thousand calls each, the sort, SAL, ten host round
+	// trips) leaves most of the GPU idle, and a small part of a batch is nearly all tail; a second pass fills it.  The second pass
+	// context is a second cs_engine (`twin`) with streams, events and every working buffer of its own and the index arrays of this one
+	// (ix, jump table, k-mer filter: aliases, never freed by the twin); everything that runs a pass takes "the engine it runs on".
+	cs_engine *twin = nullptr, *owner = nullptr;   // owner: set in the twin
+	cs_engine *last_ctx = nullptr;                 // which of the two holds the last whole-batch result (`last` lives in that one)
+	std::shared_mutex filter_rw;                   // passes hold it shared; rebuilding the k-mer filter for another min_seed_len takes it exclusively
+	int bloom_tried_k = 0;                         // last min_seed_len the filter was (re)built or found not to fit for
+	bool in_shared_pass = false;                   // a pass under filter_rw: build_kmer_filter is not to touch the filter
+	struct DevPipe *dp = nullptr;                  // cs_engine_submit_device / cs_engine_collect_device
 };
 
 // ------------------------------------------------------------------------------------------------ index files
@@ -230,6 +241,23 @@ extern "C" int cs_device_count(int *n)
 }
 
 static int build_kmer_filter(cs_engine *e, int k);
+// streams and events of one pass context (the engine itself, or its twin)
+static int create_pass_streams(cs_engine *e)
+{
+	HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+	for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+	int lo = 0, hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
+	HIP_TRY(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_r3a, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_r3b, hipEventDisableTiming));
+	HIP_TRY(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_wa, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_wb, hipEventDisableTiming));
+	HIP_TRY(hipStreamCreateWithFlags(&e->stream4, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreateWithFlags(&e->ev_wc, hipEventDisableTiming));
+	return CS_OK;
+}
 static int engine_init(cs_engine *e, const cs_index_view_t *v)
 {
 	int ndev = 0;
@@ -245,20 +273,12 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	if (opt.mem_cap < 1 || opt.mem_cap > 4096 || opt.lep_arena_mb < 1 || opt.max_raw_mb < 1 || (opt.jump_k != 0 && (opt.jump_k < 6 || opt.jump_k > 15)))
 		return fail(CS_EINVAL, "cs_engine_options_t: mem_cap 1..4096, lep_arena_mb >= 1, max_raw_mb >= 1, jump_k 0 or 6..15");
 	for (int r : opt.reserved) if (r) return fail(CS_EINVAL, "cs_engine_options_t.reserved must be 0");
+	if (opt.passes_in_flight < 1 || opt.passes_in_flight > 2 || opt.host_pack_threads < 0) return fail(CS_EINVAL, "cs_engine_options_t: passes_in_flight 1 or 2, host_pack_threads >= 0");
 	if (verbose) { fprintf(stderr, "[cs_engine] creating engine on device %d, seq_len %llu\n", e->device, (unsigned long long)v->seq_len); fflush(stderr); }
-	HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-	for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+	CS_TRY(create_pass_streams(e));
 	{
 		int lo = 0, hi = 0;
 		(void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-		HIP_TRY(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo));
-		HIP_TRY(hipEventCreateWithFlags(&e->ev_r3a, hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&e->ev_r3b, hipEventDisableTiming));
-		HIP_TRY(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
-		HIP_TRY(hipEventCreateWithFlags(&e->ev_wa, hipEventDisableTiming));
-		HIP_TRY(hipEventCreateWithFlags(&e->ev_wb, hipEventDisableTiming));
-		HIP_TRY(hipStreamCreateWithFlags(&e->stream4, hipStreamNonBlocking));
-		HIP_TRY(hipEventCreateWithFlags(&e->ev_wc, hipEventDisableTiming));
 		// The runtime multiplexes the normal-priority streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
 		// default), and a stream that shares its queue with a 30-ms download stands still for 30 ms -- measured: the seeding kernels
 		// of a sub-batch took 65 instead of 45 ms beside the download of the previous one.  So the engine keeps to three normal
@@ -420,6 +440,62 @@ static int engine_init(cs_engine *e, const cs_index_view_t *v)
 	return CS_OK;
 }
 
+// The second pass context of an engine (see cs_engine::twin): made on the first call that can use two passes at a time.
+static int twin_create(cs_engine *e)
+{
+	if (e->twin || e->owner || e->opt.passes_in_flight < 2) return CS_OK;
+	cs_engine *t = new cs_engine();
+	e->twin = t;                                  // (destroyed with e, also when the rest of this function fails)
+	t->owner = e; t->device = e->device; t->n_cu = e->n_cu; t->opt = e->opt;
+	CS_TRY(create_pass_streams(t));
+	t->ix = e->ix;
+	t->jump_k = e->jump_k; t->d_jump.p = e->d_jump.p;                 // aliases (cap stays 0): cs_engine_destroy clears them before the release
+	t->d_bloom.p = e->d_bloom.p; t->bloom_k = e->bloom_k; t->bloom_bits = e->bloom_bits;
+	t->smem_mode = e->smem_mode; t->occ_win = e->occ_win; t->occ_fwd = e->occ_fwd; t->occ_bwd = e->occ_bwd;
+	t->lep_arena_bytes = e->lep_arena_bytes; t->cap = e->cap; t->max_raw_bytes = e->max_raw_bytes; t->blocks_per_cu = e->blocks_per_cu;
+	CS_TRY(t->d_sctr.reserve(32)); CS_TRY(t->h_sctr.reserve(32));
+	CS_TRY(t->d_sst2.reserve(SST2_ENTRIES));
+	HIP_TRY(hipMemsetAsync(t->d_sst2.p, 0xff, SST2_ENTRIES * sizeof(uint4), t->stream));
+	HIP_TRY(hipMemsetAsync(t->d_sctr.p, 0, 32 * sizeof(unsigned long long), t->stream));
+	CS_TRY(t->d_ctr.reserve(8)); CS_TRY(t->h_ctr.reserve(8));
+	HIP_TRY(hipMemsetAsync(t->d_ctr.p, 0, 8 * sizeof(unsigned long long), t->stream));
+	CS_TRY(t->d_evc.reserve((size_t)N_KID * N_EV));
+	HIP_TRY(hipMemsetAsync(t->d_evc.p, 0, (size_t)N_KID * N_EV * sizeof(unsigned long long), t->stream));
+	HIP_TRY(hipStreamSynchronize(t->stream));
+	if (e->opt.verbose) { fprintf(stderr, "[cs_engine] second pass context created\n"); fflush(stderr); }
+	return CS_OK;
+}
+static void invalidate_last(cs_engine *e) { e->last.valid = false; if (e->twin) e->twin->last.valid = false; e->last_ctx = nullptr; }
+static cs_engine *pass_ctx(cs_engine *e, int ci) { return ci && e->twin ? e->twin : e; }
+static int n_pass_ctx(const cs_engine *e) { return e->twin ? 2 : 1; }
+
+// One seeding pass on context c of engine P (c == P or c == P->twin).  The k-mer filter of the window lanes belongs to P and is built
+// for one min_seed_len at a time: a pass holds filter_rw shared; a pass that wants the filter for another value waits for the others
+// to end, rebuilds it alone and starts over.  (If it cannot be had -- no room, another k in use by a pass of the blocking kind -- the
+// window lanes do without: results never depend on it.)
+static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
+                            uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out, const uint4 *d_recs);
+static int pass_on_ctx(cs_engine *P, cs_engine *c, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
+                       uint64_t n_bases, uint64_t *nm, uint64_t *ns, const uint4 *d_recs)
+{
+	const int k = par->min_seed_len;
+	auto wants_build = [&]() { return P->jump_k && P->ix.text2 && P->opt.kmer_filter && P->smem_mode == 1 && par->sst_mode != 0 && k >= 8 && k <= 24 && P->bloom_k != k && P->bloom_tried_k != k; };
+	for (;;) {
+		{
+			std::shared_lock<std::shared_mutex> sl(P->filter_rw);
+			if (!wants_build()) {
+				if (c != P) { c->d_bloom.p = P->d_bloom.p; c->bloom_k = P->bloom_k; c->bloom_bits = P->bloom_bits; }
+				c->in_shared_pass = true;
+				const int rc = seed_device_impl(c, par, n_reads, d_bases, d_off, n_bases, nm, ns, d_recs);
+				c->in_shared_pass = false;
+				return rc;
+			}
+		}
+		std::unique_lock<std::shared_mutex> ul(P->filter_rw);
+		if (wants_build()) { P->bloom_tried_k = k; CS_TRY(build_kmer_filter(P, k)); }
+	}
+}
+
 extern "C" int cs_engine_create(const cs_index_view_t *index, int device, cs_engine_t **out)
 {
 	return cs_engine_create_opts(index, device, nullptr, out);
@@ -438,13 +514,16 @@ extern "C" int cs_engine_create_opts(const cs_index_view_t *index, int device, c
 }
 
 static void pipe_stop(cs_engine *e);
+static void dev_pipe_stop(cs_engine *e);
 static bool pipe_busy(const cs_engine *e);
 extern "C" void cs_engine_destroy(cs_engine_t *e)
 {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	pipe_stop(e);
+	dev_pipe_stop(e);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	if (e->twin) { e->twin->d_jump.p = nullptr; e->twin->d_bloom.p = nullptr; cs_engine_destroy(e->twin); e->twin = nullptr; } // (its index arrays are this engine's)
 	e->d_bwt.release(); e->d_sa.release(); e->d_fsa32.release(); e->d_fsa64.release(); e->d_text2.release(); e->d_isa32.release(); e->d_isa64.release(); e->d_bloom.release(); e->d_cnt_snap.release(); e->d_pending.release(); e->d_lcp.release(); e->d_rep.release(); e->d_auxA.release(); e->d_auxB.release(); e->d_raw.release(); e->d_seq.release(); e->d_seqp.release(); e->d_off.release();
 	e->d_out.release(); e->d_out2.release(); e->d_cnt.release(); e->d_cnt2.release(); e->d_ovf.release(); e->d_spill.release();
 	e->d_ctr.release(); e->d_tmp.release(); e->d_tmp2.release(); e->d_mem_off.release(); e->d_seed_off.release(); e->d_seed_of_mem.release();
@@ -453,7 +532,8 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->d_evc.release(); e->d_sel.release(); e->d_sel_moff.release(); e->d_sel_soff.release(); e->d_sel_mems.release(); e->d_sel_seeds.release();
 	e->d_okey64.release(); e->d_okey64b.release(); e->d_okey.release(); e->d_oidx.release(); e->d_okey2.release(); e->d_oidx2.release(); e->d_sctr.release(); e->h_sctr.release();
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
-	for (int k = 0; k < 2; ++k) { e->hp_stage[k].release(); e->hp_in[k].release(); e->hp_pk_mems[k].release(); e->hp_inoff[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
+	for (int k = 0; k < 3; ++k) { e->hp_stage[k].release(); e->hp_in[k].release(); e->hp_inoff[k].release(); }
+	for (int k = 0; k < 2; ++k) { e->hp_pk_mems[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
 	for (int k = 0; k < 3; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
 	e->x_mems.release(); e->x_seeds.release();
 	for (auto &ev : e->hp_ev_done) if (ev) (void)hipEventDestroy(ev);
@@ -478,16 +558,27 @@ extern "C" int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st)
 {
 	if (!e || !st) return fail(CS_EINVAL, "null argument");
 	*st = e->st;
+	if (e->twin) { // both pass contexts count
+		const cs_stats_t &t = e->twin->st;
+		st->reads += t.reads; st->bases += t.bases; st->mems += t.mems; st->seeds += t.seeds; st->bwt_queries += t.bwt_queries; st->bwt_calls += t.bwt_calls;
+		st->sal_queries += t.sal_queries; st->sal_calls += t.sal_calls; st->overflow_mems += t.overflow_mems; st->seed_kernel_ms += t.seed_kernel_ms;
+		st->sal_kernel_ms += t.sal_kernel_ms; st->total_ms += t.total_ms; st->seed_kernel_launches += t.seed_kernel_launches; st->overflow_kernel_ms += t.overflow_kernel_ms;
+		st->overflow_kernel_launches += t.overflow_kernel_launches; st->reseed_text_calls += t.reseed_text_calls; st->reseed_index_calls += t.reseed_index_calls;
+		st->sweep_text_calls += t.sweep_text_calls; st->r3_text_seeds += t.r3_text_seeds;
+	}
 	return CS_OK;
 }
 extern "C" void cs_engine_reset_stats(cs_engine_t *e)
 {
 	if (!e || pipe_busy(e)) return; // (the seeding thread owns the counters while batches are in flight)
-	memset(&e->st, 0, sizeof e->st);
-	e->stream_bytes = 0;
 	(void)hipSetDevice(e->device);
-	(void)hipMemsetAsync(e->d_evc.p, 0, (size_t)N_KID * N_EV * sizeof(unsigned long long), e->stream);
-	(void)hipStreamSynchronize(e->stream);
+	for (int ci = 0; ci < n_pass_ctx(e); ++ci) {
+		cs_engine *c = pass_ctx(e, ci);
+		memset(&c->st, 0, sizeof c->st);
+		c->stream_bytes = 0;
+		(void)hipMemsetAsync(c->d_evc.p, 0, (size_t)N_KID * N_EV * sizeof(unsigned long long), c->stream);
+		(void)hipStreamSynchronize(c->stream);
+	}
 }
 extern "C" int cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out)
 {
@@ -496,10 +587,17 @@ extern "C" int cs_engine_traffic_model(cs_engine_t *e, cs_traffic_t *out)
 	HIP_TRY(hipSetDevice(e->device));
 	HIP_TRY(hipMemcpyAsync(&out->events[0][0], e->d_evc.p, (size_t)N_KID * N_EV * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	uint64_t stream_bytes = e->stream_bytes;
+	if (e->twin) { // both pass contexts count
+		std::vector<unsigned long long> ev2((size_t)N_KID * N_EV);
+		HIP_TRY(hipMemcpy(ev2.data(), e->twin->d_evc.p, ev2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		for (int a = 0; a < N_KID; ++a) for (int b = 0; b < N_EV; ++b) out->events[a][b] += ev2[(size_t)a * N_EV + b];
+		stream_bytes += e->twin->stream_bytes;
+	}
 	const uint64_t sa_b = e->ix.fsa64 ? 8 : 4;
 	const uint64_t eb[N_EV] = {32, 16, 8, sa_b, sa_b, 4, 8, 1, 16, 32};
 	for (int i = 0; i < N_EV; ++i) out->event_bytes[i] = eb[i];
-	out->stream_bytes = e->stream_bytes;
+	out->stream_bytes = stream_bytes;
 	return CS_OK;
 }
 
@@ -646,6 +744,7 @@ static int build_kmer_filter(cs_engine *e, int k)
 {
 	if (!e->ix.text2 || k < 8 || k > 24 || !e->opt.kmer_filter) return CS_OK;
 	if (e->bloom_k == k) return CS_OK;
+	if (e->owner || e->in_shared_pass) return CS_OK; // the filter is the owner's, and is not rebuilt under a running pass (pass_on_ctx does that, alone)
 	uint32_t bits = 10; // 2^bits words: at least seq_len / 3 of them
 	while (bits < 34 && ((uint64_t)1 << bits) * 3 < e->ix.seq_len) ++bits;
 	size_t free_b = 0, total_b = 0;
@@ -656,7 +755,7 @@ static int build_kmer_filter(cs_engine *e, int k)
 	HIP_TRY(hipMemsetAsync(e->d_bloom.p, 0, ((size_t)8) << bits, e->stream));
 	hipLaunchKernelGGL(kmer_filter_fill_kernel, dim3((unsigned)(e->n_cu * 32)), dim3(256), 0, e->stream, e->ix, k, e->d_bloom.p, bits);
 	HIP_TRY(hipGetLastError()); HIP_TRY(hipStreamSynchronize(e->stream));
-	e->bloom_k = k; e->bloom_bits = bits;
+	e->bloom_k = k; e->bloom_bits = bits; e->bloom_tried_k = k;
 	return CS_OK;
 }
 
@@ -858,7 +957,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 static bool pipe_busy(const cs_engine *e);
 // d_recs: the reads as pack_reads_kernel's records when the host made them (d_bases is then null), else null
 static int seed_device_impl(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_off,
-                            uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out, const uint4 *d_recs = nullptr)
+                            uint64_t n_bases, uint64_t *n_mems_out, uint64_t *n_seeds_out, const uint4 *d_recs)
 {
 	hipStream_t s = e->stream;
 	*n_mems_out = *n_seeds_out = 0;
@@ -1090,8 +1189,8 @@ extern "C" int cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *pa
 	if (pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_seed_batch_device: submitted batches are in flight, collect them first");
 	HIP_TRY(hipSetDevice(e->device));
 	uint64_t nm = 0, ns = 0;
-	e->last.valid = false;
-	CS_TRY(seed_device_impl(e, par, n_reads, d_bases, d_offsets, n_bases, &nm, &ns));
+	invalidate_last(e);
+	CS_TRY(seed_device_impl(e, par, n_reads, d_bases, d_offsets, n_bases, &nm, &ns, nullptr));
 	e->last.valid = true; e->last.n_reads = n_reads; e->last.n_mems = nm; e->last.n_seeds = ns; e->last.want_sal = par->want_sal;
 	out->n_reads = n_reads; out->n_mems = nm; out->n_seeds = ns;
 	out->mem_off = e->d_mem_off.p; out->mems = (const cs_intv_t *)e->d_mems.p;
@@ -1197,6 +1296,11 @@ void expand_parallel(const cs_packed_result_t &P, cs_intv_t *mems, cs_seed_t *se
 // batch n-1 run at the same time -- what kt_pipeline (main.cpp:438) does for the reference's read / process / write steps.
 // All engine state touched by seed_device_impl belongs to the seeding thread while a batch is in flight: the blocking entry
 // points (device variant, digest, gather, primitives) refuse to run then.
+static double pipe_ms() // wall clock of the verbose log lines, from the first one
+{
+	static const auto t_epoch = std::chrono::steady_clock::now();
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_epoch).count();
+}
 struct HostJob {
 	uint64_t batch = 0; int part = 0, n_parts = 0;
 	const uint8_t *bases = nullptr; const uint64_t *offsets = nullptr;
@@ -1208,13 +1312,15 @@ struct XJob { uint64_t batch; int64_t r0, n; uint64_t mem_base, nm, seed_base, n
 struct BatchState {
 	uint64_t id = ~0ull; int64_t n_reads = 0; int parts_total = 0, parts_queued = 0; uint64_t mem_base = 0, seed_base = 0;
 	int rc = CS_OK; std::string err; bool pk16 = false, sal = false, expand = false, expanded = false; int max_occ = 0;
+	int ctx = 0;                         // pass context that seeded its last part (the whole batch, if it was not cut)
 };
 struct HostPipe {
-	std::thread th_up, th_seed, th_x;
+	std::thread th_up, th_seed[2], th_x;
 	std::mutex mu; std::condition_variable cv;
 	bool started = false, quit = false;
 	std::deque<HostJob> q_up, q_seed; std::deque<XJob> q_x; bool x_busy = false;
-	int in_free[2] = {1, 1};
+	int in_free[3] = {1, 1, 1};
+	uint64_t pack_turn = 0;              // running number of the part whose results are packed and sent home next: parts are seeded by two threads, packed in order
 	std::atomic<uint64_t> n_submitted{0}, n_collected{0}; uint64_t parts_seen = 0; // (one submitting and one collecting thread may run at the same time)
 	long long handed = -1;               // batch whose pinned result slot the caller currently holds (until its next collect)
 	BatchState bs[3];                    // batch id % 3: up to three batches in flight
@@ -1228,13 +1334,13 @@ static void pipe_upload_thread(cs_engine *e)
 		HostJob j;
 		{
 			std::unique_lock<std::mutex> lk(hp.mu);
-			hp.cv.wait(lk, [&] { return hp.quit || (!hp.q_up.empty() && (hp.in_free[0] || hp.in_free[1])); });
+			hp.cv.wait(lk, [&] { return hp.quit || (!hp.q_up.empty() && (hp.in_free[0] || hp.in_free[1] || hp.in_free[2])); });
 			if (hp.quit) return;
 			j = hp.q_up.front(); hp.q_up.pop_front();
-			j.in_slot = hp.in_free[0] ? 0 : 1; hp.in_free[j.in_slot] = 0;
+			j.in_slot = hp.in_free[0] ? 0 : hp.in_free[1] ? 1 : 2; hp.in_free[j.in_slot] = 0;
 		}
 		hipError_t he = hipSuccess;
-		const auto tu0 = std::chrono::steady_clock::now();
+		const double tu0 = e->opt.verbose > 1 ? pipe_ms() : 0.0;
 		if (j.packed) {
 			// the reads as records, made here chunk by chunk: the copy of chunk i runs beside the packing of chunk i + 1
 			uint4 *st = e->hp_stage[j.in_slot].p;
@@ -1249,8 +1355,7 @@ static void pipe_upload_thread(cs_engine *e)
 		if (he == hipSuccess && j.offsets) he = hipMemcpyAsync(e->hp_inoff[j.in_slot].p, j.offsets + j.r0, ((size_t)j.n + 1) * 8, hipMemcpyHostToDevice, e->s_up);
 		if (he == hipSuccess && j.offsets) { hipLaunchKernelGGL(rebase_words_kernel, dim3(1), dim3(1024), 0, e->s_up, e->hp_inoff[j.in_slot].p, (uint64_t)j.n + 1); he = hipGetLastError(); }
 		if (he == hipSuccess) he = hipStreamSynchronize(e->s_up);
-		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %.1f MB %s in %.1f ms\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (double)(j.packed ? ((j.nb >> 5) + (uint64_t)j.n) * 16 : j.nb) / 1e6, j.packed ? "packed on the host and uploaded" : "uploaded",
-		                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
+		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %.1f MB %s in %.1f ms (from %.1f to %.1f ms)\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (double)(j.packed ? ((j.nb >> 5) + (uint64_t)j.n) * 16 : j.nb) / 1e6, j.packed ? "packed on the host and uploaded" : "uploaded", pipe_ms() - tu0, tu0, pipe_ms());
 		std::lock_guard<std::mutex> lk(hp.mu);
 		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch % 3]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
 		hp.q_seed.push_back(j);
@@ -1292,17 +1397,23 @@ static void pipe_expand_thread(cs_engine *e)
 	}
 }
 
-static void pipe_seed_thread(cs_engine *e)
+// One of the (up to) two seeding threads: thread ci runs its passes on pass context ci.  Parts are taken in order; the running number a
+// part gets when it is taken (k) fixes the order of the second stage -- packing the results and queueing their download, which needs
+// the mem / seed totals of all earlier parts of the batch -- so a part that was seeded faster than its predecessor waits for it there.
+static void pipe_seed_thread(cs_engine *e, int ci)
 {
 	HostPipe &hp = *e->hp;
 	(void)hipSetDevice(e->device);
+	cs_engine *c = pass_ctx(e, ci);
 	for (;;) {
 		HostJob j;
+		uint64_t k;
 		{
 			std::unique_lock<std::mutex> lk(hp.mu);
 			hp.cv.wait(lk, [&] { return hp.quit || !hp.q_seed.empty(); });
 			if (hp.quit) return;
 			j = hp.q_seed.front(); hp.q_seed.pop_front();
+			k = hp.parts_seen++;                       // running part number: pack slot k & 1, part events k % 4
 		}
 		const int rs = (int)(j.batch % 3);
 		BatchState &b = hp.bs[rs];
@@ -1312,16 +1423,22 @@ static void pipe_seed_thread(cs_engine *e)
 		uint64_t nm = 0, ns = 0;
 		const bool sal = j.par.want_sal != 0;
 		const size_t msz = j.pk16 ? 16 : 32;
-		const auto t0 = std::chrono::steady_clock::now();
-		if (rc == CS_OK) { rc = seed_device_impl(e, &j.par, j.n, j.packed ? nullptr : e->hp_in[j.in_slot].p, e->hp_inoff[j.in_slot].p, j.nb, &nm, &ns, j.packed ? reinterpret_cast<const uint4 *>(e->hp_in[j.in_slot].p) : nullptr); if (rc != CS_OK) err = g_err; }
-		if (e->opt.verbose) { // (with the wall clock of the seeding thread: idle gaps between parts show which neighbour it waited for)
-			static const auto t_epoch = std::chrono::steady_clock::now();
-			const auto t1 = std::chrono::steady_clock::now();
-			fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %lld reads seeded in %.1f ms (from %.1f to %.1f ms)\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (long long)j.n,
-			        std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t0 - t_epoch).count(), std::chrono::duration<double, std::milli>(t1 - t_epoch).count());
+		const double t0 = e->opt.verbose ? pipe_ms() : 0.0;
+		if (rc == CS_OK) {
+			rc = pass_on_ctx(e, c, &j.par, j.n, j.packed ? nullptr : e->hp_in[j.in_slot].p, e->hp_inoff[j.in_slot].p, j.nb, &nm, &ns, j.packed ? reinterpret_cast<const uint4 *>(e->hp_in[j.in_slot].p) : nullptr);
+			if (rc != CS_OK) err = g_err;
 		}
-		{ std::lock_guard<std::mutex> lk(hp.mu); hp.in_free[j.in_slot] = 1; hp.cv.notify_all(); } // (the reads were converted into the engine's own buffer)
-		const uint64_t k = hp.parts_seen++;                 // running part number: pack slot k & 1, part events k % 4
+		if (e->opt.verbose) { // (with the wall clock of the seeding thread: idle gaps between parts show which neighbour it waited for)
+			const double t1 = pipe_ms();
+			fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %lld reads seeded on context %d in %.1f ms (from %.1f to %.1f ms)\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (long long)j.n, ci, t1 - t0, t0, t1);
+		}
+		{ // the input slot is free again (the reads were converted into the context's own buffers); then wait for this part's turn in the second stage
+			std::unique_lock<std::mutex> lk(hp.mu);
+			hp.in_free[j.in_slot] = 1; hp.cv.notify_all();
+			hp.cv.wait(lk, [&] { return hp.quit || hp.pack_turn == k; });
+			if (hp.quit) return;
+			if (rc == CS_OK) rc = b.rc;               // (an earlier part of the batch failed meanwhile)
+		}
 		const int ps = (int)(k & 1);
 		const uint64_t mem_base = b.mem_base, seed_base = b.seed_base;
 		if (rc == CS_OK) {
@@ -1344,16 +1461,16 @@ static void pipe_seed_thread(cs_engine *e)
 		}
 		if (rc == CS_OK && (e->hp_pk_mems[ps].reserve((size_t)nm * msz + 64) != CS_OK || (sal && (e->hp_pk_rlo[ps].reserve((size_t)ns + 8) != CS_OK || e->hp_pk_rhi[ps].reserve((size_t)ns + 8) != CS_OK)))) { rc = CS_ENOMEM; err = g_err; }
 		if (rc == CS_OK) {
-			hipStream_t s = e->stream;
+			hipStream_t s = c->stream;                 // (the context's own stream: its next pass starts behind these kernels)
 			const unsigned g = (unsigned)e->n_cu * 8;
-			hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_mem_off.p, (uint64_t)j.n + 1, mem_base, e->hp_pk_moff[ps].p);
+			hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)c->d_mem_off.p, (uint64_t)j.n + 1, mem_base, e->hp_pk_moff[ps].p);
 			if (nm) {
-				if (j.pk16) hipLaunchKernelGGL(pack_mems16_kernel, dim3(g), dim3(256), 0, s, (const OutMem *)e->d_mems.p, nm, (uint4 *)e->hp_pk_mems[ps].p);
-				else hipf(hipMemcpyAsync(e->hp_pk_mems[ps].p, e->d_mems.p, (size_t)nm * 32, hipMemcpyDeviceToDevice, s), "copying mems");
+				if (j.pk16) hipLaunchKernelGGL(pack_mems16_kernel, dim3(g), dim3(256), 0, s, (const OutMem *)c->d_mems.p, nm, (uint4 *)e->hp_pk_mems[ps].p);
+				else hipf(hipMemcpyAsync(e->hp_pk_mems[ps].p, c->d_mems.p, (size_t)nm * 32, hipMemcpyDeviceToDevice, s), "copying mems");
 			}
 			if (sal) {
-				hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)e->d_seed_off.p, (uint64_t)j.n + 1, seed_base, e->hp_pk_soff[ps].p);
-				if (ns) hipLaunchKernelGGL(pack_rbeg_kernel, dim3(g), dim3(256), 0, s, (const OutSeed *)e->d_seeds.p, ns, e->hp_pk_rlo[ps].p, e->hp_pk_rhi[ps].p);
+				hipLaunchKernelGGL(shift_words_kernel, dim3(g), dim3(256), 0, s, (const uint64_t *)c->d_seed_off.p, (uint64_t)j.n + 1, seed_base, e->hp_pk_soff[ps].p);
+				if (ns) hipLaunchKernelGGL(pack_rbeg_kernel, dim3(g), dim3(256), 0, s, (const OutSeed *)c->d_seeds.p, ns, e->hp_pk_rlo[ps].p, e->hp_pk_rhi[ps].p);
 			}
 			hipf(hipGetLastError(), "pack kernels");
 			hipf(hipEventRecord(e->hp_ev_pk[ps], s), "event");
@@ -1367,14 +1484,18 @@ static void pipe_seed_thread(cs_engine *e)
 			}
 			hipf(hipEventRecord(e->hp_ev_dn[k % 4], e->s_down), "event");
 			if (j.part + 1 == j.n_parts) hipf(hipEventRecord(e->hp_ev_done[rs], e->s_down), "event");
+		} else {
+			// a failed part still owns hp_ev_dn[k % 4] in the eyes of part k + 2: leave a recorded event behind
+			(void)hipEventRecord(e->hp_ev_dn[k % 4], e->s_down);
 		}
 		std::lock_guard<std::mutex> lk(hp.mu);
 		if (rc != CS_OK && b.rc == CS_OK) { b.rc = rc; b.err = err; }
 		if (rc == CS_OK) {
-			b.mem_base += nm; b.seed_base += ns;
+			b.mem_base += nm; b.seed_base += ns; b.ctx = ci;
 			if (j.expand) { XJob x = {j.batch, j.r0, j.n, mem_base, nm, seed_base, ns, e->hp_ev_dn[k % 4], j.part + 1 == j.n_parts}; hp.q_x.push_back(x); }
 		}
 		b.parts_queued++;
+		hp.pack_turn = k + 1;
 		hp.cv.notify_all();
 	}
 }
@@ -1385,11 +1506,14 @@ static void pipe_stop(cs_engine *e)
 	HostPipe &hp = *e->hp;
 	{ std::lock_guard<std::mutex> lk(hp.mu); hp.quit = true; hp.cv.notify_all(); }
 	if (hp.th_up.joinable()) hp.th_up.join();
-	if (hp.th_seed.joinable()) hp.th_seed.join();
+	for (auto &t : hp.th_seed) if (t.joinable()) t.join();
 	if (hp.th_x.joinable()) hp.th_x.join();
 	delete e->hp; e->hp = nullptr;
 }
-static bool pipe_busy(const cs_engine *e) { return e->hp && e->hp->n_submitted.load() != e->hp->n_collected.load(); }
+static bool host_pipe_busy(const cs_engine *e) { return e->hp && e->hp->n_submitted.load() != e->hp->n_collected.load(); }
+static bool dev_pipe_busy(const cs_engine *e);
+static bool pipe_busy(const cs_engine *e) { return host_pipe_busy(e) || dev_pipe_busy(e); }
+
 
 static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets, bool expand)
 {
@@ -1397,7 +1521,8 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
 	if (par->min_seed_len < 1 || par->max_occ < 1 || par->split_width < 0) return fail(CS_EINVAL, "bad seeding parameters");
 	HIP_TRY(hipSetDevice(e->device));
-	if (!e->hp) e->hp = new HostPipe();
+	if (dev_pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_submit: device batches are in flight (cs_engine_submit_device), collect them first");
+	if (!e->hp) { CS_TRY(twin_create(e)); e->hp = new HostPipe(); } // (the seeding threads are started for the contexts that exist now)
 	HostPipe &hp = *e->hp;
 	if (hp.n_submitted.load() - hp.n_collected.load() >= 3) return fail(CS_EINVAL, "cs_engine_submit: three batches are in flight already, collect one first");
 	uint64_t n_bases = 0, max_len = 0;
@@ -1455,13 +1580,15 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 			// a reallocation frees buffers the other batch may still be using: not only while its parts are queued or being seeded
 			// (the input slots are given back right after seed_device_impl), but until the seeding thread has queued the pack kernels
 			// and downloads of its LAST part (parts_queued == parts_total) and those have drained (s_down below)
-			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.bs[(rs + 1) % 3].parts_queued == hp.bs[(rs + 1) % 3].parts_total &&
+			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.in_free[2] && hp.bs[(rs + 1) % 3].parts_queued == hp.bs[(rs + 1) % 3].parts_total &&
 			                                     hp.bs[(rs + 2) % 3].parts_queued == hp.bs[(rs + 2) % 3].parts_total); });
 			lk.unlock();
 			HIP_TRY(hipStreamSynchronize(e->stream));
+			if (e->twin) HIP_TRY(hipStreamSynchronize(e->twin->stream));
 			HIP_TRY(hipStreamSynchronize(e->s_down));
+			for (int k = 0; k < 3; ++k) { CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_stage[k].reserve(stage_cap)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); }
 			for (int k = 0; k < 2; ++k) {
-				CS_TRY(e->hp_in[k].reserve(in_cap + 64)); CS_TRY(e->hp_stage[k].reserve(stage_cap)); CS_TRY(e->hp_inoff[k].reserve(off_cap)); CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
+				CS_TRY(e->hp_pk_moff[k].reserve(off_cap));
 				if (par->want_sal) CS_TRY(e->hp_pk_soff[k].reserve(off_cap));
 			}
 			lk.lock();
@@ -1470,11 +1597,13 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 		b = BatchState();
 		b.id = id; b.n_reads = n_reads; b.parts_total = (int)kparts; b.pk16 = parts[0].pk16; b.sal = par->want_sal != 0; b.expand = expand; b.max_occ = par->max_occ;
 		for (auto &j : parts) hp.q_up.push_back(j);
+		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu submitted at %.1f ms in %d part(s)\n", (unsigned long long)id, pipe_ms(), (int)kparts);
 		hp.n_submitted++;
-		e->last.valid = false;
+		invalidate_last(e);
 		if (!hp.started) {
 			hp.started = true;
-			hp.th_up = std::thread(pipe_upload_thread, e); hp.th_seed = std::thread(pipe_seed_thread, e); hp.th_x = std::thread(pipe_expand_thread, e);
+			hp.th_up = std::thread(pipe_upload_thread, e); hp.th_x = std::thread(pipe_expand_thread, e);
+			for (int ci = 0; ci < n_pass_ctx(e); ++ci) hp.th_seed[ci] = std::thread(pipe_seed_thread, e, ci);
 		}
 		hp.cv.notify_all();
 	}
@@ -1497,10 +1626,9 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 		hp.cv.wait(lk, [&] { return b.parts_queued == b.parts_total; });
 	}
 	int rc = b.rc; std::string err = b.err;
-	const auto tc0 = std::chrono::steady_clock::now();
+	const double tc0 = e->opt.verbose > 1 ? pipe_ms() : 0.0;
 	if (rc == CS_OK && hipEventSynchronize(e->hp_ev_done[rs]) != hipSuccess) { rc = CS_EDEVICE; err = "waiting for the download"; (void)hipGetLastError(); }
-	if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu collected: waited %.1f ms for its download after its last part was queued\n", (unsigned long long)id,
-	                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+	if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu collected at %.1f ms: waited %.1f ms for its download after its last part was queued\n", (unsigned long long)id, pipe_ms(), pipe_ms() - tc0);
 	if (rc == CS_OK && b.expand) {
 		std::unique_lock<std::mutex> lk(hp.mu);
 		hp.cv.wait(lk, [&] { return b.expanded || b.rc != CS_OK; });
@@ -1520,8 +1648,100 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 	out->seed_rbeg_lo = b.sal ? e->hp_rlo[rs].p : nullptr; out->seed_rbeg_hi = b.sal ? e->hp_rhi[rs].p : nullptr;
 	{ // cs_engine_result_digest / gather_reads work on the device-side result, which is the whole batch only if it was not cut
 		std::lock_guard<std::mutex> lk(hp.mu); // (a submit on another thread invalidates it under the same lock)
-		e->last.valid = b.parts_total == 1 && !pipe_busy(e); e->last.n_reads = b.n_reads; e->last.n_mems = b.mem_base; e->last.n_seeds = b.seed_base; e->last.want_sal = b.sal;
+		cs_engine *c = pass_ctx(e, b.ctx);
+		invalidate_last(e);
+		c->last.valid = b.parts_total == 1 && !pipe_busy(e); c->last.n_reads = b.n_reads; c->last.n_mems = b.mem_base; c->last.n_seeds = b.seed_base; c->last.want_sal = b.sal;
+		e->last_ctx = c;
 	}
+	return CS_OK;
+}
+
+// ---- device batches, two in flight: cs_engine_submit_device / cs_engine_collect_device.  Batch n runs on pass context n & 1, on a thread
+// of its own, so the thin tail of one pass overlaps the dense start of the next; results come back in submission order as device
+// pointers into that context's buffers.
+struct DevPipe {
+	std::thread th[2]; std::mutex mu; std::condition_variable cv; bool quit = false;
+	int n_ctx = 1;
+	int state[2] = {0, 0};                // 0 idle, 1 queued, 2 running, 3 done
+	struct Job { cs_params_t par; int64_t n; const uint8_t *bases; const uint64_t *off; uint64_t nb; } job[2];
+	int rc[2] = {0, 0}; std::string err[2]; uint64_t nm[2] = {0, 0}, ns[2] = {0, 0};
+	std::atomic<uint64_t> n_sub{0}, n_col{0};
+};
+static bool dev_pipe_busy(const cs_engine *e) { return e->dp && e->dp->n_sub.load() != e->dp->n_col.load(); }
+static void dev_pipe_thread(cs_engine *e, int ci)
+{
+	DevPipe &dp = *e->dp;
+	(void)hipSetDevice(e->device);
+	cs_engine *c = pass_ctx(e, ci);
+	for (;;) {
+		DevPipe::Job j;
+		{
+			std::unique_lock<std::mutex> lk(dp.mu);
+			dp.cv.wait(lk, [&] { return dp.quit || dp.state[ci] == 1; });
+			if (dp.quit) return;
+			dp.state[ci] = 2; j = dp.job[ci];
+		}
+		uint64_t nm = 0, ns = 0;
+		const int rc = pass_on_ctx(e, c, &j.par, j.n, j.bases, j.off, j.nb, &nm, &ns, nullptr);
+		std::lock_guard<std::mutex> lk(dp.mu);
+		dp.rc[ci] = rc; dp.err[ci] = rc != CS_OK ? g_err : std::string(); dp.nm[ci] = nm; dp.ns[ci] = ns;
+		dp.state[ci] = 3;
+		dp.cv.notify_all();
+	}
+}
+static void dev_pipe_stop(cs_engine *e)
+{
+	if (!e->dp) return;
+	DevPipe &dp = *e->dp;
+	{ std::lock_guard<std::mutex> lk(dp.mu); dp.quit = true; dp.cv.notify_all(); }
+	for (auto &t : dp.th) if (t.joinable()) t.join();
+	delete e->dp; e->dp = nullptr;
+}
+extern "C" int cs_engine_submit_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases)
+{
+	if (!e || !par || n_reads < 0 || (n_reads > 0 && !d_offsets) || (n_bases > 0 && !d_bases)) return fail(CS_EINVAL, "cs_engine_submit_device: bad argument");
+	if (n_reads >= (int64_t)0xffffffffll) return fail(CS_ERANGE, "more than 2^32-1 reads in one call");
+	if (host_pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_submit_device: host batches are in flight (cs_engine_submit), collect them first");
+	HIP_TRY(hipSetDevice(e->device));
+	if (!e->dp) {
+		CS_TRY(twin_create(e));
+		e->dp = new DevPipe();
+		e->dp->n_ctx = n_pass_ctx(e);
+		for (int ci = 0; ci < e->dp->n_ctx; ++ci) e->dp->th[ci] = std::thread(dev_pipe_thread, e, ci);
+	}
+	DevPipe &dp = *e->dp;
+	if (dp.n_sub.load() - dp.n_col.load() >= (uint64_t)dp.n_ctx) return fail(CS_EINVAL, dp.n_ctx == 2 ? "cs_engine_submit_device: two batches are in flight already, collect one first" : "cs_engine_submit_device: a batch is in flight already (passes_in_flight = 1), collect it first");
+	const int ci = (int)(dp.n_sub.load() % (uint64_t)dp.n_ctx);
+	std::lock_guard<std::mutex> lk(dp.mu);
+	invalidate_last(e);
+	dp.job[ci] = {*par, n_reads, d_bases, d_offsets, n_bases};
+	dp.state[ci] = 1;
+	dp.n_sub++;
+	dp.cv.notify_all();
+	return CS_OK;
+}
+extern "C" int cs_engine_collect_device(cs_engine_t *e, cs_result_t *out)
+{
+	if (!e || !out) return fail(CS_EINVAL, "cs_engine_collect_device: null argument");
+	if (!e->dp || e->dp->n_sub.load() == e->dp->n_col.load()) return fail(CS_EINVAL, "cs_engine_collect_device: nothing has been submitted");
+	DevPipe &dp = *e->dp;
+	const int ci = (int)(dp.n_col.load() % (uint64_t)dp.n_ctx);
+	cs_engine *c = pass_ctx(e, ci);
+	int rc; std::string err; uint64_t nm, ns; bool sal; int64_t n;
+	{
+		std::unique_lock<std::mutex> lk(dp.mu);
+		dp.cv.wait(lk, [&] { return dp.state[ci] == 3; });
+		rc = dp.rc[ci]; err = dp.err[ci]; nm = dp.nm[ci]; ns = dp.ns[ci]; sal = dp.job[ci].par.want_sal != 0; n = dp.job[ci].n;
+		dp.state[ci] = 0;
+		dp.n_col++;
+	}
+	memset(out, 0, sizeof *out);
+	if (rc != CS_OK) return fail(rc, err);
+	invalidate_last(e);
+	c->last.valid = true; c->last.n_reads = n; c->last.n_mems = nm; c->last.n_seeds = ns; c->last.want_sal = sal; e->last_ctx = c;
+	out->n_reads = n; out->n_mems = nm; out->n_seeds = ns;
+	out->mem_off = c->d_mem_off.p; out->mems = (const cs_intv_t *)c->d_mems.p;
+	out->seed_off = sal ? c->d_seed_off.p : nullptr; out->seeds = sal ? (const cs_seed_t *)c->d_seeds.p : nullptr;
 	return CS_OK;
 }
 
@@ -1567,10 +1787,11 @@ __global__ void digest_kernel(const uint64_t *w, uint64_t n, unsigned long long 
 	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
 	if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-extern "C" int cs_engine_result_digest(cs_engine_t *e, cs_digest_t *out)
+extern "C" int cs_engine_result_digest(cs_engine_t *e0, cs_digest_t *out)
 {
-	if (!e || !out) return fail(CS_EINVAL, "null argument");
-	if (!e->last.valid || pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_result_digest: no whole-batch result is held on the device (call a seed function first)");
+	if (!e0 || !out) return fail(CS_EINVAL, "null argument");
+	cs_engine *e = e0->last_ctx ? e0->last_ctx : e0;  // the pass context that holds the result; everything below runs on it
+	if (!e->last.valid || pipe_busy(e0)) return fail(CS_EINVAL, "cs_engine_result_digest: no whole-batch result is held on the device (call a seed function first)");
 	HIP_TRY(hipSetDevice(e->device));
 	hipStream_t s = e->stream;
 	HIP_TRY(hipMemsetAsync(e->d_ctr.p, 0, 4 * sizeof(unsigned long long), s));
@@ -1611,10 +1832,11 @@ __global__ void sel_copy_kernel(const uint64_t *ids, int64_t n_sel, const uint64
 	for (uint64_t j = a, n = om[t + 1] - om[t]; j < n; j += 16) out_m[om[t] + j] = mems[mem_off[r] + j];
 	if (seeds) for (uint64_t j = a, n = os[t + 1] - os[t]; j < n; j += 16) out_s[os[t] + j] = seeds[seed_off[r] + j];
 }
-extern "C" int cs_engine_gather_reads(cs_engine_t *e, int64_t n_sel, const uint64_t *read_ids, cs_result_t *out)
+extern "C" int cs_engine_gather_reads(cs_engine_t *e0, int64_t n_sel, const uint64_t *read_ids, cs_result_t *out)
 {
-	if (!e || !out || n_sel < 0 || (n_sel > 0 && !read_ids)) return fail(CS_EINVAL, "cs_engine_gather_reads: bad argument");
-	if (!e->last.valid || pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_gather_reads: no whole-batch result is held on the device (call a seed function first)");
+	if (!e0 || !out || n_sel < 0 || (n_sel > 0 && !read_ids)) return fail(CS_EINVAL, "cs_engine_gather_reads: bad argument");
+	cs_engine *e = e0->last_ctx ? e0->last_ctx : e0;  // the pass context that holds the result; everything below runs on it
+	if (!e->last.valid || pipe_busy(e0)) return fail(CS_EINVAL, "cs_engine_gather_reads: no whole-batch result is held on the device (call a seed function first)");
 	HIP_TRY(hipSetDevice(e->device));
 	hipStream_t s = e->stream;
 	const bool sal = e->last.want_sal != 0;

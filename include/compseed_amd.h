@@ -99,7 +99,10 @@ typedef struct {
 	int32_t verbose;          /* [0] progress lines on stderr                                                                 */
 	int32_t host_pack_threads;/* [8] host variants: the reads are turned into the kernels' 16-byte / 32-base records by this many
 	                           *     host threads and cross PCIe as 0.6 bytes per base; 0 = upload the caller's bytes, pack on the GPU */
-	int32_t reserved[4];      /* must be 0 */
+	int32_t passes_in_flight; /* [2] seeding passes the engine runs at the same time (parts of a blocking call, batches of a stream, device
+	                           *     batches of cs_engine_submit_device): the thin tail of one pass is filled by the next.  2 costs a second
+	                           *     set of working buffers (allocated on first use); 1 = one pass at a time                          */
+	int32_t reserved[3];      /* must be 0 */
 } cs_engine_options_t;
 
 /* CSR result of one batch.  Read r owns mems[mem_off[r] .. mem_off[r+1]) sorted by info (comp_seed.cpp:2301) and
@@ -194,6 +197,16 @@ int  cs_engine_seed_batch(cs_engine_t *e, const cs_params_t *par, int64_t n_read
                           const uint8_t *bases, const uint64_t *offsets, cs_result_t *out);
 int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                                  const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases, cs_result_t *out);
+/* The device variant as a stream of batches, up to TWO in flight (cs_engine_options_t.passes_in_flight): batch n is seeded on pass
+ * context n & 1 -- a second set of streams and working buffers over the same index -- so the thin tail of one pass (late iterations,
+ * sort, SAL, host round trips) runs beside the dense start of the next; this is how a worker that keeps its reads in HBM drives the engine
+ * (the reference's kt_for over chunks of a batch, comp_seed.cpp:2541-2548, is the same overlap on CPU threads).  Inputs as for
+ * cs_engine_seed_batch_device, and they must stay untouched until their batch has been collected.  Results come back in submission
+ * order; the device pointers of a collected batch stay valid until the SECOND submit after its collect (the next batch on its context).
+ * While device batches are in flight the other entry points that use the device return CS_EINVAL. */
+int  cs_engine_submit_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
+                             const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases);
+int  cs_engine_collect_device(cs_engine_t *e, cs_result_t *out);
 
 /* ---- packed results: what actually crosses PCIe.  A 10 M-read batch produces ~80 M mems and ~200 M seeds, 5.9 GB as cs_intv_t /
  *      cs_seed_t -- more transfer time than seeding time -- but half of those bytes are implied: a seed's qbeg and len are its

@@ -637,3 +637,89 @@ def test_submit_growing_batches_while_the_other_is_in_flight():
                 e.submit(jobs[i + depth][0], jobs[i + depth][1])
         e.close()
     ix.close()
+
+
+def _download_result(eng, r, n_reads):
+    import compseed_amd as ca
+    mo = eng.download(r.ptr["mem_off"], np.uint64, n_reads + 1)
+    mm = eng.download(r.ptr["mems"], ca.INTV_DT, r.n_mems)
+    so = eng.download(r.ptr["seed_off"], np.uint64, n_reads + 1)
+    ss = eng.download(r.ptr["seeds"], ca.SEED_DT, r.n_seeds)
+    return mo, mm, so, ss
+
+
+@pytest.mark.parametrize("passes", [2, 1])
+def test_device_batches_in_flight_on_two_pass_contexts(passes):
+    """cs_engine_submit_device / cs_engine_collect_device: every golden run as a stream of device-resident batches, two in flight on
+    alternating pass contexts (own -k / -r / -y / -c / -s per batch: the k-mer filter is rebuilt between passes that run at the same
+    time); results in submission order, bit for bit; a collected result stays valid while the next batch runs; misuse is an error code"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    e = ca.Engine(ix, 0, passes_in_flight=passes)
+    runs = _data.golden_runs()
+    dev = []
+    for name, pname in runs:
+        z, kw = _data.load_golden(name, pname)
+        bases, off = _data.load_reads(name)
+        d_b = e.alloc(bases.nbytes + 64); d_o = e.alloc(off.nbytes)
+        e.upload(d_b, bases); e.upload(d_o, off)
+        dev.append((z, kw, d_b, d_o, off.size - 1, bases.size))
+    with pytest.raises(ca.CSError):
+        e.collect_device()                                   # nothing submitted
+
+    def sub(i):
+        z, kw, d_b, d_o, n, nb = dev[i]
+        e.submit_device(d_b, d_o, n, nb, ca.Params(**kw))
+    for i in range(passes):
+        sub(i)
+    with pytest.raises(ca.CSError):
+        sub(passes)                                          # that many are in flight already
+    with pytest.raises(ca.CSError):
+        e.seed_batch_device(dev[0][2], dev[0][3], dev[0][4], dev[0][5])      # blocking calls refuse meanwhile
+    host_b, host_o = _data.load_reads(runs[0][0])
+    with pytest.raises(ca.CSError):
+        e.submit(host_b, host_o)                             # and so does the host pipeline
+    for i in range(len(runs)):
+        r = e.collect_device()
+        if i + passes < len(runs):
+            sub(i + passes)                                  # the next batch starts; r's context is not reused before the submit after this one
+        z, n = dev[i][0], dev[i][4]
+        mo, mm, so, ss = _download_result(e, r, n)
+        assert np.array_equal(mo, z["mem_off"]) and np.array_equal(np.stack([mm["x0"], mm["x1"], mm["x2"], mm["info"]], axis=1), z["mems"]), runs[i]
+        assert np.array_equal(so, z["seed_off"]) and np.array_equal(ss["rbeg"], z["seed_rbeg"]) and np.array_equal(ss["qbeg"], z["seed_qbeg"]) and np.array_equal(ss["len"], z["seed_len"]), runs[i]
+    dg = e.result_digest()                                   # the last batch is still held by its context
+    z, kw, d_b, d_o, n, nb = dev[-1]
+    e.seed_batch_device(d_b, d_o, n, nb, ca.Params(**kw))
+    assert e.result_digest() == dg
+    st = e.stats()
+    assert st["reads"] == sum(d[4] for d in dev) + n
+    for d in dev:
+        e.free(d[2]); e.free(d[3])
+    e.close(); ix.close()
+
+
+def test_stream_of_host_batches_with_changing_parameters():
+    """cs_engine_submit / collect: all golden runs through the host pipeline, three in flight, parts seeded on two pass contexts and
+    packed in order; consecutive batches differ in -k, so the k-mer filter is rebuilt while the other context is busy"""
+    import compseed_amd as ca
+    ix = ca.Index.load(_data.PREFIX)
+    for pr in (700, 0):
+        e = ca.Engine(ix, 0, pipeline_reads=pr)
+        runs = _data.golden_runs()
+        data = []
+        for name, pname in runs:
+            z, kw = _data.load_golden(name, pname)
+            bases, off = _data.load_reads(name)
+            data.append((z, kw, bases, off))
+        for i in range(3):
+            e.submit(data[i][2], data[i][3], ca.Params(**data[i][1]))
+        for i in range(len(runs)):
+            p = e.collect_packed()
+            z = data[i][0]
+            mems, seeds = _expand_packed(p)
+            assert np.array_equal(p["mem_off"], z["mem_off"]) and np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), z["mems"]), runs[i]
+            assert np.array_equal(seeds["rbeg"], z["seed_rbeg"]) and np.array_equal(p["seed_off"], z["seed_off"]), runs[i]
+            if i + 3 < len(runs):
+                e.submit(data[i + 3][2], data[i + 3][3], ca.Params(**data[i + 3][1]))
+        e.close()
+    ix.close()

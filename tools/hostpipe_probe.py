@@ -1,4 +1,5 @@
-"""tools/hostpipe_probe.py -- timeline of the host pipeline (cs_engine_seed_batch_packed) at bench scale, for several sub-batch sizes."""
+"""tools/hostpipe_probe.py -- timeline of the host pipeline at bench scale (engine log at verbose = 2): one blocking packed call, one
+expanded call, and a stream of batches with three in flight.  usage: hostpipe_probe.py [genome_mbp] [reads] [key=value engine options ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -6,30 +7,36 @@ import numpy as np, torch
 import compseed_amd as ca, synth
 mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 3100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+opts = {k: int(v) for k, v in (a.split("=") for a in sys.argv[3:])}
 G = synth.make_genome(int(mbp * 1e6), seed=20261003, device="cuda")
 ix = ca.Index.build(G.cpu().numpy(), 0)
 bases, off = synth.make_reads(G, n, 150, seed=777, p_sub=0.005, sort=True)
 del G; torch.cuda.empty_cache()
 pin = ca.pinned_array(bases.numel()); pin[:] = bases.cpu().numpy(); ho = off.cpu().numpy().astype(np.uint64)
-for pr in [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "5000000", "2500000", "1250000"])]:
-    eng = ca.Engine(ix, 0, pipeline_reads=pr, verbose=0)
+eng = ca.Engine(ix, 0, verbose=0, **opts)
+for _ in range(3):
+    eng.seed_batch_packed(pin, ho)                                       # sizes the buffers (three result slots)
+eng.close()
+eng = ca.Engine(ix, 0, verbose=2, **opts)
+for _ in range(3):
     eng.seed_batch_packed(pin, ho)
-    eng.close()
-    eng = ca.Engine(ix, 0, pipeline_reads=pr, verbose=1)
-    eng.seed_batch_packed(pin, ho); eng.seed_batch_packed(pin, ho)      # sizes the buffers (two result slots)
-    print("---- pipeline_reads", pr, flush=True); sys.stderr.flush()
-    t = time.perf_counter(); eng.seed_batch_packed(pin, ho); dt = time.perf_counter() - t
-    print("packed: %.1f ms -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
-    eng.seed_batch(pin, ho, copy=False)
-    t = time.perf_counter(); eng.seed_batch(pin, ho, copy=False); dt = time.perf_counter() - t
-    print("expanded: %.1f ms -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
-    eng.submit(pin, ho); eng.submit(pin, ho); eng.collect_packed(); eng.submit(pin, ho)
-    t = time.perf_counter()
-    for i in range(4):
-        eng.collect_packed()
-        if i < 3:
-            eng.submit(pin, ho)
-    dt = (time.perf_counter() - t) / 4
+print("---- one blocking packed call", flush=True); sys.stderr.flush()
+t = time.perf_counter(); eng.seed_batch_packed(pin, ho); dt = time.perf_counter() - t
+sys.stderr.flush(); print("packed: %.1f ms -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+eng.seed_batch(pin, ho, copy=False)
+print("---- one blocking expanded call", flush=True)
+t = time.perf_counter(); eng.seed_batch(pin, ho, copy=False); dt = time.perf_counter() - t
+sys.stderr.flush(); print("expanded: %.1f ms -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+print("---- stream, three in flight", flush=True)
+for _ in range(3):
+    eng.submit(pin, ho)
+for i in range(10):
     eng.collect_packed()
-    print("stream of batches, two in flight: %.1f ms per batch -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
-    eng.close()
+    if i == 3:
+        t = time.perf_counter()
+    if i == 8:
+        dt = (time.perf_counter() - t) / 5
+    if i < 7:
+        eng.submit(pin, ho)
+sys.stderr.flush(); print("stream of batches, three in flight: %.1f ms per batch -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+eng.close()
