@@ -76,6 +76,8 @@ def parse_args():
     ap.add_argument("--side-workloads", default="repeat50",
                     help="comma-separated workload profiles measured after the headline in a child run of this script (N = 1 only; '' = none): "
                          "reported under `workloads`, never part of `value`")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="device batches kept in flight in the timed region (cs_engine_submit_device / collect_device; 1 = one blocking cs_engine_seed_batch_device per step)")
     ap.add_argument("--no-extension", action="store_true", help="skip the seed-extension side measurement (`extension` key)")
     ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)  # internal: a child run for `workloads`
     ap.add_argument("--index-broadcast", action="store_true",
@@ -282,18 +284,47 @@ def main():
         eng.close(); ix.close()
         return 0
 
-    if args.warmup == 0:
-        step()  # never time the first call of an engine: it sizes and allocates the batch buffers (setup, like the index upload)
-    for _ in range(args.warmup):
-        res = step()
+    def run_steps(k, in_flight):
+        """k steps = k passes of the hot path over the batch, every one complete when this returns.  in_flight 2: the steps go through
+        cs_engine_submit_device / cs_engine_collect_device, two at a time on the engine's two pass contexts (the tail of one pass beside
+        the start of the next -- how a worker with a queue of device-resident batches drives the engine); 1: one blocking call per step"""
+        r_ = None
+        if in_flight <= 1:
+            for _ in range(k):
+                r_ = step()
+            return r_
+        for _ in range(min(in_flight, k)):
+            eng.submit_device(bases.data_ptr(), off.data_ptr(), args.reads, n_bases, par)
+        for i in range(k):
+            r_ = eng.collect_device()
+            if i + in_flight < k:
+                eng.submit_device(bases.data_ptr(), off.data_ptr(), args.reads, n_bases, par)
+        return r_
+
+    in_flight = min(args.in_flight, int(eng.options.passes_in_flight))
+    step()  # never time the first call of an engine: it sizes and allocates the batch buffers (setup, like the index upload)
+    if in_flight > 1:
+        run_steps(2, in_flight)  # ... of both pass contexts
+    run_steps(args.warmup, in_flight)
     eng.reset_stats()
     D.barrier()
+    torch.cuda.synchronize()
     ts = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps, in_flight)
+    torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - ts)
-    st = eng.stats()
+    st_timed = eng.stats()
+    # the same steps one at a time (blocking calls): the HIP-event times of the stage mean "the stage alone on the GPU" only here, so
+    # the roofline below is taken from this run; with two passes in flight the stages of two passes overlap and stretch each other
+    if in_flight > 1:
+        eng.reset_stats()
+        t1_ = time.perf_counter()
+        run_steps(args.steps, 1)
+        serial_ms = 1e3 * (time.perf_counter() - t1_) / args.steps
+        st = eng.stats()
+    else:
+        st, serial_ms = st_timed, 1e3 * elapsed / args.steps
 
     total_reads = args.reads * world * args.steps
     value = total_reads / elapsed
@@ -301,6 +332,8 @@ def main():
         "metric": "reads/sec (150bp) seeded", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "steps_in_flight": in_flight,
+        "one_step_at_a_time": {"ms_per_step": serial_ms, "reads_per_s": args.reads / (serial_ms * 1e-3), "note": "rank 0: the same steps as blocking cs_engine_seed_batch_device calls"},
         "config": {"workload": "%s; %d x %d bp %s reads per GPU per step; -k %d -r %g -y %d -c %d%s" %
                                (prof["describe"](args.genome_mbp), args.reads, args.read_len, "position-sorted" if rkw.get("sort", True) else "shuffled",
                                 args.k, args.r, args.y, args.c, " (mems only)" if args.no_sal else " + SAL"),
@@ -374,6 +407,11 @@ def main():
             "traffic": stage_traffic,
             "kernel": "SMEM stage = all fwd0 / fwd / bwd_win / bwd_win0 / bwd_wide / r2text / r3text launches of one pass (%d reads)" % int(reads_per_launch),
             "kernel_ms_per_launch": kern_ms, "launches": launches,
+            "measured_with": "one step at a time (blocking calls)" if in_flight > 1 else "the timed region",
+            "two_passes_in_flight": ({"stage_span_ms_per_pass": st_timed["seed_kernel_ms"] / max(1, st_timed["seed_kernel_launches"]), "ms_per_step": 1e3 * elapsed / args.steps,
+                                      "model_bytes_over_step_time_frac": model_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "the timed region: two passes overlap, so a pass's stage span is longer than alone while a step takes less; the last figure divides "
+                                              "the stage's model bytes by the WHOLE step time (stage + sort + SAL)"} if in_flight > 1 else None),
             "model": "bytes the kernels request from the index-side arrays (32-B Occ records, jump entries, filter words, SA / inverse-SA "
                      "entries, text words, rep/lcp bytes, LEP entries) counted on the device + streamed queue / read / mem bytes "
                      "(cs_engine_traffic_model); a lower bound of what this implementation has to fetch",
@@ -463,7 +501,7 @@ def main():
             reps = 3
 
             def timed(fn):
-                fn(); fn(); fn()                              # warm-up: the three pinned result slots / the host buffers are sized on first use
+                fn(); fn(); fn(); fn()                        # warm-up: the four pinned result slots / the host buffers are sized on first use
                 tp = time.perf_counter()
                 for _ in range(reps):
                     r_ = fn()
@@ -482,11 +520,12 @@ def main():
                 ok_p = ok_p and np.array_equal(ca.packed_rbeg(rp, sel_s), want["seeds"]["rbeg"])
             # a stream of batches, three in flight (cs_engine_submit / cs_engine_collect_packed): upload of batch n+1, seeding of batch n
             # and download of batch n-1 overlap -- how the reference drives this stage (kt_pipeline, main.cpp:438)
-            # steady state of a long stream: 16 batches go through, three kept in flight from the first to the last; the clock runs from the
-            # completion of the 5th to the completion of the 13th (8 batches) -- the pipeline is full before, during and after the timed window
+            # steady state of a long stream: 20 batches go through, three kept in flight from the first to the last; the clock runs from the
+            # completion of the 7th to the completion of the 17th (10 batches) -- the pipeline is full before, during and after the timed window
             # (filling it takes three batches, and a batch submitted to an idle engine is cut into parts: neither belongs to the rate)
-            n_total, first, nstream = 16, 4, 8
-            for _ in range(3):
+            n_total, first, nstream = 20, 6, 10
+            depth = 3                                        # (the engine takes four; with one more the uploads run beside more of the downloads and both get slower)
+            for _ in range(depth):
                 eng.submit(hb_pin, ho_all, par)
             for i in range(n_total):
                 rs_ = eng.collect_packed()
@@ -494,7 +533,7 @@ def main():
                     tp = time.perf_counter()
                 if i == first + nstream:
                     dt_s = (time.perf_counter() - tp) / nstream
-                if i + 3 < n_total:
+                if i + depth < n_total:
                     eng.submit(hb_pin, ho_all, par)
             while True:
                 try:

@@ -57,7 +57,7 @@ extern "C" void cs_engine_options_default(cs_engine_options_t *o)
 	if (!o) return;
 	memset(o, 0, sizeof *o);
 	o->full_sa = 1; o->sa64 = 0; o->text_mode = 1; o->text_arrays = 1; o->jump_k = 15; o->kmer_filter = 1; o->fused = 0;
-	o->mem_cap = 64; o->lep_arena_mb = 32768; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
+	o->mem_cap = 64; o->lep_arena_mb = 16384; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
 	o->pipeline_reads = 5000000; o->expand_threads = 16; o->host_pack_threads = 8; o->passes_in_flight = 2;
 }
 
@@ -115,6 +115,7 @@ template <typename T> struct PinBuf {
 	void release() { if (p) (void)hipHostFree(p); p = nullptr; dp = nullptr; cap = 0; }
 };
 
+constexpr int PIPE_DEPTH = 4; // batches in flight in the host pipeline (cs_engine_submit): one pinned result slot each
 struct cs_engine {
 	int device = 0;
 	int n_cu = 256;
@@ -148,10 +149,10 @@ struct cs_engine {
 	int occ_fwd = 4, occ_bwd = 4; // resident 256-thread blocks per CU of fwd_kernel / bwd_kernel
 	size_t lep_arena_bytes = (size_t)32 << 30;
 	// host variants (seed_host_pipelined): copy streams, three input slots, two pack slots, pinned packed results, expanded results
-	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[3] = {nullptr, nullptr, nullptr};
+	hipStream_t s_up = nullptr, s_down = nullptr; hipEvent_t hp_ev_pk[2] = {nullptr, nullptr}, hp_ev_dn[4] = {nullptr, nullptr, nullptr, nullptr}, hp_ev_done[PIPE_DEPTH] = {};
 	PinBuf<uint4> hp_stage[3]; // records made by the host (host_pack.cpp), staged for the upload into hp_in[slot]
 	DevBuf<uint8_t> hp_in[3], hp_pk_mems[2]; DevBuf<uint64_t> hp_inoff[3], hp_pk_moff[2], hp_pk_soff[2]; DevBuf<uint32_t> hp_pk_rlo[2]; DevBuf<uint8_t> hp_pk_rhi[2]; // seeds: low words and fifth bytes of rbeg
-	PinBuf<uint64_t> hp_moff[3], hp_soff[3]; PinBuf<uint8_t> hp_mems[3]; PinBuf<uint32_t> hp_rlo[3]; PinBuf<uint8_t> hp_rhi[3]; // three pinned result slots (slot = batch % 3)
+	PinBuf<uint64_t> hp_moff[PIPE_DEPTH], hp_soff[PIPE_DEPTH]; PinBuf<uint8_t> hp_mems[PIPE_DEPTH]; PinBuf<uint32_t> hp_rlo[PIPE_DEPTH]; PinBuf<uint8_t> hp_rhi[PIPE_DEPTH]; // pinned result slots (slot = batch % PIPE_DEPTH)
 	struct HostPipe *hp = nullptr;
 	HostBuf<cs_intv_t> x_mems; HostBuf<cs_seed_t> x_seeds;
 	cs_stats_t st{};
@@ -534,7 +535,7 @@ extern "C" void cs_engine_destroy(cs_engine_t *e)
 	e->h_mem_off.release(); e->h_seed_off.release(); e->h_mems.release(); e->h_seeds.release(); e->h_ctr.release();
 	for (int k = 0; k < 3; ++k) { e->hp_stage[k].release(); e->hp_in[k].release(); e->hp_inoff[k].release(); }
 	for (int k = 0; k < 2; ++k) { e->hp_pk_mems[k].release(); e->hp_pk_moff[k].release(); e->hp_pk_soff[k].release(); e->hp_pk_rlo[k].release(); e->hp_pk_rhi[k].release(); }
-	for (int k = 0; k < 3; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
+	for (int k = 0; k < PIPE_DEPTH; ++k) { e->hp_moff[k].release(); e->hp_soff[k].release(); e->hp_mems[k].release(); e->hp_rlo[k].release(); e->hp_rhi[k].release(); }
 	e->x_mems.release(); e->x_seeds.release();
 	for (auto &ev : e->hp_ev_done) if (ev) (void)hipEventDestroy(ev);
 	for (auto &ev : e->hp_ev_pk) if (ev) (void)hipEventDestroy(ev);
@@ -1323,7 +1324,7 @@ struct HostPipe {
 	uint64_t pack_turn = 0;              // running number of the part whose results are packed and sent home next: parts are seeded by two threads, packed in order
 	std::atomic<uint64_t> n_submitted{0}, n_collected{0}; uint64_t parts_seen = 0; // (one submitting and one collecting thread may run at the same time)
 	long long handed = -1;               // batch whose pinned result slot the caller currently holds (until its next collect)
-	BatchState bs[3];                    // batch id % 3: up to three batches in flight
+	BatchState bs[PIPE_DEPTH];           // batch id % PIPE_DEPTH
 };
 
 static void pipe_upload_thread(cs_engine *e)
@@ -1357,7 +1358,7 @@ static void pipe_upload_thread(cs_engine *e)
 		if (he == hipSuccess) he = hipStreamSynchronize(e->s_up);
 		if (e->opt.verbose > 1) fprintf(stderr, "[cs_engine] batch %llu part %d/%d: %.1f MB %s in %.1f ms (from %.1f to %.1f ms)\n", (unsigned long long)j.batch, j.part + 1, j.n_parts, (double)(j.packed ? ((j.nb >> 5) + (uint64_t)j.n) * 16 : j.nb) / 1e6, j.packed ? "packed on the host and uploaded" : "uploaded", pipe_ms() - tu0, tu0, pipe_ms());
 		std::lock_guard<std::mutex> lk(hp.mu);
-		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch % 3]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
+		if (he != hipSuccess) { (void)hipGetLastError(); BatchState &b = hp.bs[j.batch % PIPE_DEPTH]; if (b.rc == CS_OK) { b.rc = CS_EDEVICE; b.err = std::string("upload: ") + hipGetErrorString(he); } }
 		hp.q_seed.push_back(j);
 		hp.cv.notify_all();
 	}
@@ -1375,8 +1376,8 @@ static void pipe_expand_thread(cs_engine *e)
 			if (hp.quit) return;
 			x = hp.q_x.front(); hp.q_x.pop_front(); hp.x_busy = true;
 		}
-		BatchState &b = hp.bs[x.batch % 3];
-		const int rs = (int)(x.batch % 3);
+		BatchState &b = hp.bs[x.batch % PIPE_DEPTH];
+		const int rs = (int)(x.batch % PIPE_DEPTH);
 		bool ok = hipEventSynchronize(x.ev) == hipSuccess;
 		if (ok) {
 			const double scale = x.last ? 1.0 : (double)b.n_reads / (double)(x.r0 + x.n) * ((x.r0 + x.n) * 4 < b.n_reads ? 1.2 : 1.08); // room for the whole batch at the first growth
@@ -1415,7 +1416,7 @@ static void pipe_seed_thread(cs_engine *e, int ci)
 			j = hp.q_seed.front(); hp.q_seed.pop_front();
 			k = hp.parts_seen++;                       // running part number: pack slot k & 1, part events k % 4
 		}
-		const int rs = (int)(j.batch % 3);
+		const int rs = (int)(j.batch % PIPE_DEPTH);
 		BatchState &b = hp.bs[rs];
 		int rc; { std::lock_guard<std::mutex> lk(hp.mu); rc = b.rc; }
 		std::string err;
@@ -1445,7 +1446,7 @@ static void pipe_seed_thread(cs_engine *e, int ci)
 			// the pack buffers of this slot were last used by the part before the previous one: its download must be over
 			if (k >= 2) hipf(hipEventSynchronize(e->hp_ev_dn[(k - 2) % 4]), "waiting for a download");
 			// the batch that used this pinned result slot before may still be in the caller's hands: wait until it is given back
-			{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || hp.handed < 0 || (uint64_t)hp.handed == j.batch || (uint64_t)hp.handed % 3 != j.batch % 3; }); if (hp.quit) return; }
+			{ std::unique_lock<std::mutex> lk(hp.mu); hp.cv.wait(lk, [&] { return hp.quit || hp.handed < 0 || (uint64_t)hp.handed == j.batch || (uint64_t)hp.handed % PIPE_DEPTH != j.batch % PIPE_DEPTH; }); if (hp.quit) return; }
 			// (from here on the result slot is this batch's) offsets: one entry per read + 1
 			if (j.part == 0 && (e->hp_moff[rs].reserve((size_t)j.n_reads + 1) != CS_OK || (sal && e->hp_soff[rs].reserve((size_t)j.n_reads + 1) != CS_OK))) { rc = CS_ENOMEM; err = g_err; }
 			// pinned room for the whole batch: estimated from its first part, grown (keeping what has arrived) if that was too little
@@ -1522,22 +1523,29 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	if (par->min_seed_len < 1 || par->max_occ < 1 || par->split_width < 0) return fail(CS_EINVAL, "bad seeding parameters");
 	HIP_TRY(hipSetDevice(e->device));
 	if (dev_pipe_busy(e)) return fail(CS_EINVAL, "cs_engine_submit: device batches are in flight (cs_engine_submit_device), collect them first");
-	if (!e->hp) { CS_TRY(twin_create(e)); e->hp = new HostPipe(); } // (the seeding threads are started for the contexts that exist now)
+	if (!e->hp) e->hp = new HostPipe();
 	HostPipe &hp = *e->hp;
-	if (hp.n_submitted.load() - hp.n_collected.load() >= 3) return fail(CS_EINVAL, "cs_engine_submit: three batches are in flight already, collect one first");
+	if (hp.n_submitted.load() - hp.n_collected.load() >= (uint64_t)PIPE_DEPTH) return fail(CS_EINVAL, "cs_engine_submit: four batches are in flight already, collect one first");
 	uint64_t n_bases = 0, max_len = 0;
 	if (n_reads > 0) {
 		if (offsets[0] != 0) return fail(CS_EINVAL, "offsets[0] must be 0");
 		n_bases = offsets[n_reads];
 		if (n_bases > 0 && !bases) return fail(CS_EINVAL, "bases is null");
-		for (int64_t r = 0; r < n_reads; ++r) {
-			if (offsets[r + 1] < offsets[r]) return fail(CS_EINVAL, "offsets must start at 0, be non-decreasing and end at n_bases");
-			max_len = std::max(max_len, offsets[r + 1] - offsets[r]);
-		}
+		// (10 M offsets are 6 ms on one thread, in front of everything else a blocking call does: four threads)
+		const int vt = n_reads >= (1 << 20) ? 4 : 1;
+		uint64_t vmax[4] = {0, 0, 0, 0}; bool vbad[4] = {false, false, false, false};
+		auto vrange = [&](int t) {
+			uint64_t m = 0; bool bad = false;
+			for (int64_t r = n_reads * t / vt, r1 = n_reads * (t + 1) / vt; r < r1; ++r) { bad |= offsets[r + 1] < offsets[r]; m = std::max(m, offsets[r + 1] - offsets[r]); }
+			vmax[t] = m; vbad[t] = bad;
+		};
+		if (vt == 1) vrange(0);
+		else { std::thread th[3]; for (int t = 1; t < vt; ++t) th[t - 1] = std::thread(vrange, t); vrange(0); for (auto &t : th) t.join(); }
+		for (int t = 0; t < vt; ++t) { if (vbad[t]) return fail(CS_EINVAL, "offsets must start at 0, be non-decreasing and end at n_bases"); max_len = std::max(max_len, vmax[t]); }
 		if (max_len >= 65535) return fail(CS_ERANGE, "read length exceeds the limit 65535 (MAX_READ_LEN)");
 	}
 	const uint64_t id = hp.n_submitted.load();
-	const int rs = (int)(id % 3);
+	const int rs = (int)(id % PIPE_DEPTH);
 	// parts: contiguous read ranges of about pipeline_reads reads (one, if the batch is not much larger than that)
 	std::vector<HostJob> parts;
 	const int64_t per = e->opt.pipeline_reads > 0 ? e->opt.pipeline_reads : std::max<int64_t>(n_reads, 1);
@@ -1548,14 +1556,14 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 	// upload (79 ms) is longer than the seeding of batch n+1 (55 ms): measured 92 ms per batch whole against 65 ms in parts.
 	const bool streaming = hp.n_submitted.load() - hp.n_collected.load() >= 2 && !expand;
 	// part boundaries.  A batch that has the engine to itself (a blocking call, the first batch of a stream) cannot hide the upload of its
-	// first part or the download of its last one behind anything, so those two are made small (0.3 of the nominal part) and the rest is
-	// cut into parts of about 0.7: 10 M reads at 5 M nominal = 1.5 / 3.5 / 3.5 / 1.5 M.
+	// first part or the download of its last one behind anything, so those two are made small (0.2 of the nominal part) and the rest is
+	// cut into parts of about 0.8: 10 M reads at 5 M nominal = 1 / 4 / 4 / 1 M (measured against 1.5 / 3.5 / 3.5 / 1.5: section 8 of DESIGN.md).
 	std::vector<int64_t> cut(1, 0);
 	const int64_t even = std::max<int64_t>(1, (n_reads + per / 2) / per);
 	if (streaming || even < 2) cut.push_back(n_reads);
 	else {
-		const int64_t h = std::max<int64_t>(1, std::min<int64_t>(n_reads / 4, per * 3 / 10)), rest = n_reads - 2 * h;
-		const int64_t km = std::max<int64_t>(1, (rest + per * 7 / 20) / std::max<int64_t>(1, per * 7 / 10));
+		const int64_t h = std::max<int64_t>(1, std::min<int64_t>(n_reads / 4, per * 2 / 10)), rest = n_reads - 2 * h;
+		const int64_t km = std::max<int64_t>(1, (rest + per * 8 / 20) / std::max<int64_t>(1, per * 8 / 10));
 		cut.push_back(h);
 		for (int64_t i = 1; i <= km; ++i) cut.push_back(h + rest * i / km);
 		cut.push_back(n_reads);
@@ -1580,8 +1588,8 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 			// a reallocation frees buffers the other batch may still be using: not only while its parts are queued or being seeded
 			// (the input slots are given back right after seed_device_impl), but until the seeding thread has queued the pack kernels
 			// and downloads of its LAST part (parts_queued == parts_total) and those have drained (s_down below)
-			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.in_free[2] && hp.bs[(rs + 1) % 3].parts_queued == hp.bs[(rs + 1) % 3].parts_total &&
-			                                     hp.bs[(rs + 2) % 3].parts_queued == hp.bs[(rs + 2) % 3].parts_total); });
+			auto others_queued = [&] { for (int o = 1; o < PIPE_DEPTH; ++o) { const BatchState &ob = hp.bs[(rs + o) % PIPE_DEPTH]; if (ob.parts_queued != ob.parts_total) return false; } return true; };
+			hp.cv.wait(lk, [&] { return hp.quit || (hp.q_up.empty() && hp.q_seed.empty() && hp.in_free[0] && hp.in_free[1] && hp.in_free[2] && others_queued()); });
 			lk.unlock();
 			HIP_TRY(hipStreamSynchronize(e->stream));
 			if (e->twin) HIP_TRY(hipStreamSynchronize(e->twin->stream));
@@ -1603,7 +1611,13 @@ static int pipe_submit(cs_engine *e, const cs_params_t *par, int64_t n_reads, co
 		if (!hp.started) {
 			hp.started = true;
 			hp.th_up = std::thread(pipe_upload_thread, e); hp.th_x = std::thread(pipe_expand_thread, e);
-			for (int ci = 0; ci < n_pass_ctx(e); ++ci) hp.th_seed[ci] = std::thread(pipe_seed_thread, e, ci);
+			// One seeding thread / pass context here.  The code takes two (parts are seeded by whichever thread is free and packed in order), and
+			// that was measured at hg19 scale: a stream of batches 59-65 instead of 57 ms per batch, a blocking call 107 instead of 105 ms --
+			// two passes that run side by side end together, their downloads queue up behind each other (the stream is within 20 % of what the
+			// 246 bytes per read of results allow over PCIe), and the next uploads wait for a free slot.  The device-resident form
+			// (cs_engine_submit_device) is where the second context pays: 48 instead of 55 ms per 10 M reads.
+			const int n_host_ctx = 1;
+			for (int ci = 0; ci < n_host_ctx && ci < n_pass_ctx(e); ++ci) hp.th_seed[ci] = std::thread(pipe_seed_thread, e, ci);
 		}
 		hp.cv.notify_all();
 	}
@@ -1617,7 +1631,7 @@ static int pipe_collect(cs_engine *e, cs_packed_result_t *out)
 	HIP_TRY(hipSetDevice(e->device));
 	HostPipe &hp = *e->hp;
 	const uint64_t id = hp.n_collected.load();
-	const int rs = (int)(id % 3);
+	const int rs = (int)(id % PIPE_DEPTH);
 	BatchState &b = hp.bs[rs];
 	{
 		std::unique_lock<std::mutex> lk(hp.mu);

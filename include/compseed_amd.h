@@ -88,7 +88,7 @@ typedef struct {
 	int32_t kmer_filter;      /* [1] filter over all min_seed_len-mers of the text for the window lanes                       */
 	int32_t fused;            /* [0] 1: the fused one-lane-per-read kernel instead of the split forward/backward kernels      */
 	int32_t mem_cap;          /* [64] mems per read held in the first-pass arena (more go through the overflow records)       */
-	int64_t lep_arena_mb;     /* [32768] arena of the forward passes' left-extension points; smaller = more chunks per pass   */
+	int64_t lep_arena_mb;     /* [16384] arena of the forward passes' left-extension points, per pass context; smaller = more chunks per pass */
 	int64_t max_raw_mb;       /* [24576] first-pass mem arena; smaller = a batch is processed in more sub-batches             */
 	int32_t r3_text_iter;     /* [4] forward launch after which round 3 starts on its side stream                             */
 	int32_t pipeline_reads;   /* [5000000] reads per sub-batch of the host variants (cs_engine_seed_batch, _packed): upload of the next,
@@ -240,12 +240,14 @@ static inline int64_t cs_packed_seed_rbeg(const cs_packed_result_t *r, uint64_t 
 int  cs_engine_seed_batch_packed(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                                  const uint8_t *bases, const uint64_t *offsets, cs_packed_result_t *out);
 /* The same as a pipeline across batches, the counterpart of the reference's kt_pipeline (main.cpp:438: read chunk n+1 while chunk n is
- * processed and chunk n-1 written): cs_engine_submit queues a batch and returns at once (at most THREE in flight; the caller's buffers
+ * processed and chunk n-1 written): cs_engine_submit queues a batch and returns at once (at most FOUR in flight; the caller's buffers
  * must stay untouched until the batch is collected), cs_engine_collect_packed blocks until the OLDEST submitted batch is complete.  With
- * batches kept submitted the upload of batch n+1, the seeding of batch n and the download of batch n-1 overlap, and throughput is that of the
- * slowest of the three instead of their sum.  Two in flight (what a two-thread kt_pipeline gives) leaves a gap: batch n+2 can only be
- * submitted when collect(n) has returned, i.e. after download(n), and its upload then has to fit into what is left of the seeding of n+1;
- * a caller that can keep three submitted closes it.  A collected result stays valid until the next collect or blocking seed call.
+ * batches kept submitted the upload of batch n+1, the seeding of batch n (of two batches at a time, on the engine's two pass contexts) and
+ * the download of batch n-1 overlap, and throughput is that of the slowest stage instead of their sum.  How many to keep submitted: a batch
+ * spends upload + seeding + download in the engine, and a new one enters only when the oldest has been collected, so the stream runs at
+ * (that latency) / (batches in flight) per batch until the slowest stage takes over -- two in flight (what a two-thread kt_pipeline gives)
+ * leave the engine idle half of the time, three to four keep it busy.  A collected result stays valid until the next collect or blocking
+ * seed call.
  * While batches are in flight the engine's other entry points that use the device return CS_EINVAL (cs_engine_reset_stats does nothing).
  * Threads: cs_engine_submit may be called from ONE thread while cs_engine_collect_packed runs on ONE other thread (the reader and the
  * processing step of a kt_pipeline, main.cpp:60-126); everything else on an engine needs the caller's own serialisation. */

@@ -14,9 +14,9 @@
 
 struct cs_engine {
 	cso_index_t ix;
-	struct { cs_params_t par; int64_t n; const uint8_t *bases; const uint64_t *off; } q[3];
+	struct { cs_params_t par; int64_t n; const uint8_t *bases; const uint64_t *off; } q[4];
 	uint64_t n_sub, n_col;
-	struct { uint64_t *mem_off, *seed_off; cs_mem16_t *mems; uint32_t *rlo; uint8_t *rhi; } res[3];
+	struct { uint64_t *mem_off, *seed_off; cs_mem16_t *mems; uint32_t *rlo; uint8_t *rhi; } res[4];
 	cs_stats_t st;
 };
 static const char *g_err = "";
@@ -46,15 +46,15 @@ void cs_engine_destroy(cs_engine_t *e)
 int cs_engine_stats(const cs_engine_t *e, cs_stats_t *st) { *st = e->st; return CS_OK; }
 int cs_engine_submit(cs_engine_t *e, const cs_params_t *par, int64_t n_reads, const uint8_t *bases, const uint64_t *offsets)
 {
-	if (e->n_sub - e->n_col >= 3) { g_err = "three batches are in flight already"; return CS_EINVAL; }
-	int k = (int)(e->n_sub++ % 3);
+	if (e->n_sub - e->n_col >= 4) { g_err = "four batches are in flight already"; return CS_EINVAL; }
+	int k = (int)(e->n_sub++ % 4);
 	e->q[k].par = *par; e->q[k].n = n_reads; e->q[k].bases = bases; e->q[k].off = offsets;
 	return CS_OK;
 }
 int cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out)
 {
 	if (e->n_sub == e->n_col) { g_err = "nothing has been submitted"; return CS_EINVAL; }
-	int k = (int)(e->n_col++ % 3);
+	int k = (int)(e->n_col++ % 4);
 	cso_params_t op = {e->q[k].par.min_seed_len, e->q[k].par.split_factor, e->q[k].par.split_width, e->q[k].par.max_occ, e->q[k].par.max_mem_intv};
 	uint64_t *mo = NULL, *so = NULL; cso_intv_t *mm = NULL; cso_seed_t *ss = NULL; cso_stats_t st;
 	if (cso_seed_batch(&e->ix, &op, e->q[k].n, e->q[k].bases, e->q[k].off, 1, 512, 1, 4, &mo, &mm, &so, &ss, &st)) { g_err = "oracle failed"; return CS_EDEVICE; }

@@ -80,8 +80,8 @@ def test_engine_options_default(lib):
     import compseed_amd as ca
     o = ca.EngineOptions()
     assert (o.full_sa, o.sa64, o.text_mode, o.text_arrays, o.jump_k, o.kmer_filter, o.fused, o.mem_cap) == (1, 0, 1, 1, 15, 1, 0, 64)
-    assert (o.lep_arena_mb, o.max_raw_mb, o.count_sal_merged, o.verbose) == (32768, 24576, 0, 0) and not any(o.reserved)
-    assert (o.pipeline_reads, o.expand_threads) == (5000000, 16)
+    assert (o.lep_arena_mb, o.max_raw_mb, o.count_sal_merged, o.verbose) == (16384, 24576, 0, 0) and not any(o.reserved)
+    assert (o.pipeline_reads, o.expand_threads, o.host_pack_threads, o.passes_in_flight) == (5000000, 16, 8, 2)
     with pytest.raises(TypeError):
         ca.EngineOptions(no_such_option=1)
 

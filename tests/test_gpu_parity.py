@@ -531,7 +531,7 @@ def test_packed_falls_back_to_full_records_for_long_reads(eng):
 
 
 def test_submit_collect_pipeline_across_batches():
-    """cs_engine_submit / cs_engine_collect_packed: three batches in flight, results come back in submission order and equal the goldens;
+    """cs_engine_submit / cs_engine_collect_packed: batches in flight (four at most), results come back in submission order and equal the goldens;
     a collected result stays intact while later batches are submitted, seeded and downloaded; misuse is an error code"""
     import compseed_amd as ca
     ix = ca.Index.load(_data.PREFIX)
@@ -545,9 +545,9 @@ def test_submit_collect_pipeline_across_batches():
         data.append((z, pin, off))
     with pytest.raises(ca.CSError):
         e.collect_packed()                                   # nothing submitted
-    e.submit(data[0][1], data[0][2]); e.submit(data[1][1], data[1][2]); e.submit(data[2][1], data[2][2])
+    e.submit(data[0][1], data[0][2]); e.submit(data[1][1], data[1][2]); e.submit(data[2][1], data[2][2]); e.submit(data[3][1], data[3][2])
     with pytest.raises(ca.CSError):
-        e.submit(data[3][1], data[3][2])                     # three in flight already
+        e.submit(data[4][1], data[4][2])                     # four in flight already
     with pytest.raises(ca.CSError):
         e.seed_batch(data[2][1], data[2][2])                 # blocking calls refuse while batches are in flight
     held = None
@@ -559,8 +559,8 @@ def test_submit_collect_pipeline_across_batches():
         mems, seeds = _expand_packed(p)
         assert np.array_equal(p["mem_off"], z["mem_off"]) and np.array_equal(np.stack([mems["x0"], mems["x1"], mems["x2"], mems["info"]], axis=1), z["mems"]), runs[i]
         assert np.array_equal(seeds["rbeg"], z["seed_rbeg"]) and np.array_equal(p["seed_off"], z["seed_off"]), runs[i]
-        if i + 3 < len(runs):
-            e.submit(data[i + 3][1], data[i + 3][2])         # keep three in flight
+        if i + 4 < len(runs):
+            e.submit(data[i + 4][1], data[i + 4][2])         # keep four in flight
             import time
             time.sleep(0.05)                                 # let the next batches run: the held result must not change under us
             m2, s2 = _expand_packed(p)
@@ -623,7 +623,7 @@ def test_submit_growing_batches_while_the_other_is_in_flight():
         for j, sz in enumerate(sizes):
             k0 = (j * 131 + rnd * 17) % (n - sz + 1)
             jobs.append(sub(k0, k0 + sz))
-        depth = 2 + (rnd & 1)                                                      # two in flight (what the reference's kt_pipeline keeps) or three
+        depth = 2 + rnd                                                            # two in flight (what the reference's kt_pipeline keeps), three, four
         for j in range(depth):
             e.submit(jobs[j][0], jobs[j][1])
         for i in range(len(jobs)):
@@ -699,8 +699,8 @@ def test_device_batches_in_flight_on_two_pass_contexts(passes):
 
 
 def test_stream_of_host_batches_with_changing_parameters():
-    """cs_engine_submit / collect: all golden runs through the host pipeline, three in flight, parts seeded on two pass contexts and
-    packed in order; consecutive batches differ in -k, so the k-mer filter is rebuilt while the other context is busy"""
+    """cs_engine_submit / collect: all golden runs through the host pipeline, three in flight, whole and cut into parts that are packed in
+    order; consecutive batches differ in -k, so the k-mer filter is rebuilt between passes (under the lock the pass contexts share)"""
     import compseed_amd as ca
     ix = ca.Index.load(_data.PREFIX)
     for pr in (700, 0):

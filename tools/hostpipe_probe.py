@@ -27,16 +27,15 @@ eng.seed_batch(pin, ho, copy=False)
 print("---- one blocking expanded call", flush=True)
 t = time.perf_counter(); eng.seed_batch(pin, ho, copy=False); dt = time.perf_counter() - t
 sys.stderr.flush(); print("expanded: %.1f ms -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
-print("---- stream, three in flight", flush=True)
-for _ in range(3):
+print("---- stream, four in flight", flush=True)
+depth, total = 4, 24
+for _ in range(depth):
     eng.submit(pin, ho)
-for i in range(10):
-    eng.collect_packed()
-    if i == 3:
-        t = time.perf_counter()
-    if i == 8:
-        dt = (time.perf_counter() - t) / 5
-    if i < 7:
+tt = []
+for i in range(total):
+    eng.collect_packed(); tt.append(time.perf_counter())
+    if i + depth < total:
         eng.submit(pin, ho)
-sys.stderr.flush(); print("stream of batches, three in flight: %.1f ms per batch -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+dt = (tt[20] - tt[8]) / 12
+sys.stderr.flush(); print("stream of batches, four in flight: %.1f ms per batch -> %.1f M reads/s" % (dt * 1e3, n / dt / 1e6), flush=True)
 eng.close()
