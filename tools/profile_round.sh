@@ -3,7 +3,8 @@
 #   gpurun --timeout 900 -- 'tools/profile_round.sh r02_final'
 # 1. <tag>_bench.json           plain `python bench.py` (steps 5): the line the numbers in DESIGN.md come from; its roofline.traffic and per-kernel
 #                               FETCH_SIZE are measured inside the run by a rocprofv3 --pmc child (counters in a pass of their own)
-# 2. <tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1` (our kernels and rocPRIM only)
+# 2. <tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1 --in-flight 1` (one pass at a time, so that a kernel's
+#                               duration is its own; our kernels and rocPRIM only)
 #    <tag>_stage_span.json      first-start-to-last-end span of the SMEM stage per pass + every launch of the last pass
 # 3. <tag>_sq_counters.txt      rocprofv3 --pmc SQ_* summed per kernel (4 M reads, one pass): issue-slot use, waiting
 # 4. <tag>_kernel_table.md      the per-kernel table (tools/kernel_table.py): model bytes, FETCH_SIZE, ms, fraction of peak, VALU-busy
@@ -12,7 +13,7 @@ tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp; ulimit -c 0
 O=$R/gpurun_out
 python3 $R/bench.py --steps 5 --warmup 2 > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-host-io --traffic none > $O/${tag}_bench_profiled.json 2> /tmp/prof_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --in-flight 1 --cpu-seconds 0 --no-host-io --traffic none --no-extension --side-workloads "" > $O/${tag}_bench_profiled.json 2> /tmp/prof_$tag.err
 python3 - "$tag" <<'PY'
 import csv, glob, sys, os, json
 tag = sys.argv[1]; R = os.environ["GRAFT_REPO_ROOT"]
@@ -41,7 +42,7 @@ out = [{"span_ms": (p[1] - p[0]) / 1e6, "launches": p[2], "summed_kernel_ms": p[
 json.dump({"passes": out, "last_pass_launches_name_startms_durms": launches}, open(os.path.join(R, "gpurun_out", tag + "_stage_span.json"), "w"), indent=1)
 print(json.dumps(out))
 PY
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/sq_$tag -- python3 $R/bench.py --reads 4000000 --steps 1 --warmup 0 --cpu-seconds 0 --no-host-io --traffic none --check-reads 1000 > /tmp/sq_$tag.json 2> /tmp/sq_$tag.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/sq_$tag -- python3 $R/bench.py --reads 4000000 --steps 1 --warmup 0 --in-flight 1 --cpu-seconds 0 --no-host-io --traffic none --check-reads 1000 --no-extension --side-workloads "" > /tmp/sq_$tag.json 2> /tmp/sq_$tag.err
 python3 - "$tag" > $O/${tag}_sq_counters.txt <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
