@@ -12,7 +12,7 @@ SEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])          
 # every symbol include/compseed_amd.h declares (tests check the library exports exactly these)
 SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", "cs_index_view", "cs_index_free", "cs_index_build",
            "cs_index_build_flags", "cs_index_save", "cs_refseq_from_fasta", "cs_refseq_codes", "cs_refseq_save", "cs_refseq_free", "cs_index_build_fasta", "cs_reader_open", "cs_reader_next", "cs_reader_close",
-           "cs_chainer_create", "cs_chainer_destroy", "cs_chain_params_default", "cs_chain_batch",
+           "cs_chainer_create", "cs_chainer_destroy", "cs_chain_params_default", "cs_chain_batch", "cs_flt_params_default", "cs_chain_filter",
            "cs_device_count", "cs_engine_options_default", "cs_engine_create", "cs_engine_create_opts", "cs_engine_destroy", "cs_engine_seed_batch",
            "cs_engine_seed_batch_device", "cs_engine_submit_device", "cs_engine_collect_device", "cs_engine_seed_batch_packed", "cs_engine_submit", "cs_engine_collect_packed", "cs_unpack_mem", "cs_mem_seed_count", "cs_host_alloc", "cs_host_free", "cs_pack_reads",
            "cs_engine_result_digest", "cs_engine_gather_reads", "cs_engine_traffic_model", "cs_engine_stats", "cs_engine_reset_stats", "cs_engine_occ4",
@@ -81,6 +81,21 @@ class ChainParams(C.Structure):
 
     def __init__(self, w=100, max_chain_gap=10000, k=19, c=500):
         super().__init__(w, max_chain_gap, k, c)
+
+
+class FltParams(C.Structure):
+    """cs_flt_params_t; defaults = mem_opt_init (mapping/comp_seed.cpp:26-58)"""
+    _fields_ = [("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32), ("max_chain_gap", C.c_int32), ("min_seed_len", C.c_int32),
+                ("mask_level", C.c_float), ("drop_ratio", C.c_float), ("a", C.c_int32), ("b", C.c_int32), ("o_del", C.c_int32), ("e_del", C.c_int32),
+                ("o_ins", C.c_int32), ("e_ins", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        load_library().cs_flt_params_default(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("no such field: " + k)
+            setattr(self, k, v)
 
 
 class CChainResult(C.Structure):
@@ -272,6 +287,9 @@ def load_library():
     L.cs_chain_params_default.argtypes = [C.POINTER(ChainParams)]
     L.cs_chain_params_default.restype = None
     L.cs_chain_batch.argtypes = [vp, C.POINTER(ChainParams), C.POINTER(CResult), vp, C.c_int, C.POINTER(CChainResult)]
+    L.cs_flt_params_default.argtypes = [C.POINTER(FltParams)]
+    L.cs_flt_params_default.restype = None
+    L.cs_chain_filter.argtypes = [vp, C.POINTER(FltParams), C.POINTER(CChainResult), vp, vp, C.c_int, C.POINTER(CChainResult), C.POINTER(vp)]
     L.cs_device_count.argtypes = [C.POINTER(C.c_int)]
     L.cs_engine_create.argtypes = [C.POINTER(IndexView), C.c_int, C.POINTER(vp)]
     L.cs_engine_destroy.argtypes = [vp]
@@ -476,6 +494,23 @@ class Chainer:
         _check(load_library().cs_chain_batch(self._h, C.byref(params), C.byref(res), ro.ctypes.data, int(threads), C.byref(out)))
         return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1), chains=_view(out.chains, CHAIN_DT, int(out.n_chains)),
                     cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds)))
+
+    def filter(self, chain_off, chains, cseed_off, cseeds, bases, read_offsets, params=None, threads=4):
+        """cs_chain_filter (mem_chain_flt + mem_flt_chained_seeds): chains as chain() returns them -> the same dict for the surviving
+        chains in the reference's order, plus cseed_score (int32 per surviving seed); copies"""
+        params = params or FltParams()
+        chain_off = np.ascontiguousarray(chain_off, dtype=np.uint64); cseed_off = np.ascontiguousarray(cseed_off, dtype=np.uint64)
+        chains = np.ascontiguousarray(chains, dtype=CHAIN_DT); cseeds = np.ascontiguousarray(cseeds, dtype=SEED_DT)
+        ro = np.ascontiguousarray(read_offsets, dtype=np.uint64)
+        bases = None if bases is None else np.ascontiguousarray(bases, dtype=np.uint8)
+        cin = CChainResult(chain_off.size - 1, chains.size, cseeds.size, chain_off.ctypes.data, chains.ctypes.data if chains.size else None, cseed_off.ctypes.data,
+                           cseeds.ctypes.data if cseeds.size else None)
+        out = CChainResult(); sc = C.c_void_p()
+        _check(load_library().cs_chain_filter(self._h, C.byref(params), C.byref(cin), bases.ctypes.data if bases is not None and bases.size else None, ro.ctypes.data,
+                                              int(threads), C.byref(out), C.byref(sc)))
+        return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1), chains=_view(out.chains, CHAIN_DT, int(out.n_chains)),
+                    cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds)),
+                    cseed_score=_view(sc.value, "<i4", int(out.n_seeds)))
 
     def close(self):
         if self._h:

@@ -43,15 +43,8 @@ inline int contig_at(const cs_refseq_view &R, int64_t fwd_pos) // (bns_pos2rid, 
 	if (fwd_pos >= R.l_pac) return -1;
 	return (int)(std::upper_bound(R.offset.begin(), R.offset.end(), fwd_pos) - R.offset.begin()) - 1;
 }
-inline uint8_t pac_base(const std::vector<uint8_t> &pac, int64_t p) { return (uint8_t)((pac[(size_t)(p >> 2)] >> ((~p & 3) << 1)) & 3); }
-
-// ASCII -> code as the reference's table does it (nst_nt4_table, bntseq.c:46-63): ACGT in either case 0..3, '-' 5, everything else 4;
-// bytes 0..4 are codes already (comp_seed.cpp:2258-2260 converts only bytes above 4)
-inline uint8_t base_code(uint8_t c)
-{
-	if (c <= 4) return c;
-	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
-}
+inline uint8_t pac_base(const std::vector<uint8_t> &pac, int64_t p) { return cs_pac_base_(pac, p); }
+inline uint8_t base_code(uint8_t c) { return cs_base_code_(c); }
 
 struct Job { uint32_t reg; int64_t q_off, t_off; int32_t qlen, tlen; }; // an extension still to run: region (global index) + its pair
 } // namespace
@@ -74,15 +67,8 @@ extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_pa
 	if (o.a < 1 || o.b < 0 || o.e_del < 1 || o.e_ins < 1 || o.o_del < 0 || o.o_ins < 0 || o.w < 1 || o.zdrop < 0) { delete A; return cs_fail_(CS_EINVAL, "cs_aligner_create: bad scoring parameters"); }
 	int rc = cs_load_contigs_(prefix, A->ref);
 	if (rc != CS_OK) { delete A; return rc; }
-	{ // <prefix>.pac: l_pac / 4 bytes (+1 if l_pac % 4), a zero byte if l_pac % 4 == 0, then l_pac % 4 (bntseq.c:316-324)
-		FILE *fp = fopen((std::string(prefix) + ".pac").c_str(), "rb");
-		if (!fp) { delete A; return cs_fail_(CS_EIO, std::string("cannot read ") + prefix + ".pac"); }
-		const size_t need = (size_t)(A->ref.l_pac >> 2) + 1;
-		A->pac.assign(need + 8, 0);
-		const size_t got = fread(A->pac.data(), 1, need, fp);
-		fclose(fp);
-		if (got < (size_t)((A->ref.l_pac + 3) >> 2)) { delete A; return cs_fail_(CS_EIO, std::string(prefix) + ".pac is truncated"); }
-	}
+	rc = cs_load_pac_(prefix, A->ref.l_pac, A->pac);
+	if (rc != CS_OK) { delete A; return rc; }
 	cs_ext_params_t xp;
 	for (int i = 0, k = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) xp.mat[k++] = (int8_t)(i == 4 || j == 4 ? -1 : i == j ? o.a : -o.b); // bwa_fill_scmat (bwalib/bwa.c:17-29)
 	xp.o_del = o.o_del; xp.e_del = o.e_del; xp.o_ins = o.o_ins; xp.e_ins = o.e_ins; xp.zdrop = o.zdrop; xp.end_bonus = o.pen_clip5; xp.flags = 0;

@@ -20,7 +20,6 @@
 #include <unordered_map>
 #include <vector>
 
-struct cs_chainer { cs_refseq_view ref; std::vector<cs_chain_t> chains; std::vector<uint64_t> chain_off, cseed_off; std::vector<cs_seed_t> cseeds; };
 
 namespace {
 constexpr int BT = 5, BMAX = 2 * BT - 1; // kb_init(chn, 512) with a 40-byte key: t = ((512 - 4 - 8) / (8 + 40) + 1) >> 1 = 5 (cstl/kbtree.h:57-62)
@@ -226,6 +225,7 @@ extern "C" int cs_chainer_create(const char *prefix, cs_chainer_t **out)
 	cs_chainer *c = new cs_chainer();
 	const int rc = cs_load_contigs_(prefix, c->ref);
 	if (rc != CS_OK) { delete c; return rc; }
+	c->prefix = prefix;
 	*out = c;
 	return CS_OK;
 }

@@ -15,6 +15,23 @@ int cs_fail_(int code, const std::string &msg); // records the calling thread's 
 // contig table of an index (<prefix>.ann, ALT flags from <prefix>.alt): shared by the chainer and the extension driver
 struct cs_refseq_view { int64_t l_pac; std::vector<int64_t> offset; std::vector<int32_t> len; std::vector<uint8_t> is_alt; };
 int cs_load_contigs_(const char *prefix, cs_refseq_view &ref);
+int cs_load_pac_(const char *prefix, int64_t l_pac, std::vector<uint8_t> &pac); // <prefix>.pac: four bases per byte, first base in the top bits (bntseq.c:236-237)
+inline uint8_t cs_pac_base_(const std::vector<uint8_t> &pac, int64_t p) { return (uint8_t)((pac[(size_t)(p >> 2)] >> ((~p & 3) << 1)) & 3); }
+// ASCII -> code as the reference's table does it (nst_nt4_table, bntseq.c:46-63): ACGT in either case 0..3, '-' 5, everything else 4;
+// bytes 0..4 are codes already (comp_seed.cpp:2258-2260 converts only bytes above 4)
+inline uint8_t cs_base_code_(uint8_t c)
+{
+	if (c <= 4) return c;
+	switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
+}
+
+// the chainer (chain.cpp: cs_chain_batch; chain_filter.cpp: cs_chain_filter)
+struct cs_chainer {
+	cs_refseq_view ref; std::string prefix;
+	std::vector<cs_chain_t> chains; std::vector<uint64_t> chain_off, cseed_off; std::vector<cs_seed_t> cseeds;                          // cs_chain_batch's result
+	std::vector<uint8_t> pac;                                                                                                            // loaded when cs_chain_filter first needs it
+	std::vector<cs_chain_t> f_chains; std::vector<uint64_t> f_chain_off, f_cseed_off; std::vector<cs_seed_t> f_cseeds; std::vector<int32_t> f_score; // cs_chain_filter's
+};
 
 // the reads of a part as 16-byte records of 32 bases, made on host threads (host_pack.cpp; bit-identical to pack_reads_kernel's)
 void cs_pack_reads_host_(const uint8_t *bases, const uint64_t *offsets, int64_t r0, int64_t n, int64_t lo, int64_t hi, void *rec_out, int threads, int force_scalar);

@@ -305,6 +305,20 @@ void cs_chain_params_default(cs_chain_params_t *p);
 int  cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, const cs_result_t *seeds, const uint64_t *read_offsets, int n_threads,
                     cs_chain_result_t *out);
 
+/* ---- the chain filters between chaining and extension (comp_seed.cpp:2364-2367), host code: mem_chain_flt (comp_seed.cpp:297-360: chains
+ *      by descending weight -- klib's introsort, whose order among equal weights is reproduced --, chains shadowed on the read by a much
+ *      heavier one dropped, the first shadowed chain of each kept one retained) and mem_flt_chained_seeds (comp_seed.cpp:393-412: for reads
+ *      of ~700 bases and more, short seeds whose neighbourhood does not reach a local alignment score of 5.5 ln(read length) are dropped and
+ *      the others carry that score; ksw_align2's number, bwalib/ksw.c:343).  `in`: cs_chain_batch's result (or the caller's chains in that
+ *      form); `out`: the surviving chains per read in the reference's order, `cseed_score` their seeds' scores -- what cs_extend_chains takes.
+ *      `bases` / <prefix>.pac are read only when a read is long enough for the seed test.  The result belongs to the chainer and stays
+ *      valid until its next cs_chain_filter. */
+typedef struct { int32_t min_chain_weight, max_chain_extend, max_chain_gap, min_seed_len; float mask_level, drop_ratio;   /* mem_opt_t: min_chain_weight (-W), max_chain_extend, max_chain_gap, -k, mask_level, drop_ratio (-D) */
+                 int32_t a, b, o_del, e_del, o_ins, e_ins; } cs_flt_params_t;                                              /* ... -A -B -O -E (the seed test) */
+void cs_flt_params_default(cs_flt_params_t *p);
+int  cs_chain_filter(cs_chainer_t *c, const cs_flt_params_t *par, const cs_chain_result_t *in, const uint8_t *bases, const uint64_t *read_offsets,
+                     int n_threads, cs_chain_result_t *out, const int32_t **cseed_score);
+
 /* ---- seed extension: the banded Smith-Waterman extensions of mem_chain2aln_across_reads_V2 (mapping/comp_seed.cpp:1319), i.e.
  *      what the reference hands to BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (mapping/bandedSWA.h:117-167; call sites
  *      comp_seed.cpp:1719,1790,1859,1942,2003,2074), computed on the GPU with the exact semantics of ksw_extend2 (bwalib/ksw.c:380-479): band of

@@ -17,6 +17,7 @@ What is produced (all data, no reference source text):
                                      recorded from its own run, and known answers of its scalar ksw_extend2
   aln1/                              `make_golden.py aln`: the reference's extension stage (mem_chain2aln_across_reads_V2): filtered chains in, alignment regions out
   c2/config2.json                    `make_golden.py bigref`: md5 of bwaidx's five files for a 64 Mbp genome (its bwt_bwtgen2 branch)
+  flt1/                              `make_golden.py flt`: 90 long reads (800-1500 bases): the reference's unfiltered chains, and what its two chain filters leave (+ regions)
   alt1/                              `make_golden.py alt`: main100's chains with a <prefix>.alt file naming chr2 (is_alt of the chains)
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
                                      md5 digests of its complete output (`make_golden.py config1` regenerates only this)
@@ -363,6 +364,77 @@ def make_aln():
     print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
 
 
+def make_flt():
+    """flt1/: reads long enough for mem_flt_chained_seeds (comp_seed.cpp:393: from ~700 bases).  90 reads of 800-1500 bases from g1's
+    reference, either strand, 4 % substitutions, a short insertion or deletion every ~150 bases, and in every third read a 120-260-base
+    stretch replaced by a copy of another place of the reference with 15 % substitutions (short seeds in a poor neighbourhood: what the
+    seed test drops).  For each: the reference's unfiltered chains (--chains) and what goes into its extension stage plus the regions
+    that come out (--aln)."""
+    import gzip, tempfile
+    d = os.path.join(HERE, "flt1"); os.makedirs(d, exist_ok=True)
+    g1 = os.path.join(HERE, "g1")
+    fa = gzip.open(os.path.join(g1, "ref.fa.gz")).read().decode().split(">")[1:]
+    contigs = ["".join(c.split("\n")[1:]).upper().replace("N", "A") for c in fa]
+    rng = np.random.default_rng(20261004)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+    def mutate(sq, p_sub, indel_every):
+        out = []
+        i = 0
+        nxt = int(rng.integers(indel_every // 2, indel_every * 3 // 2)) if indel_every else 1 << 30
+        while i < len(sq):
+            if i == nxt:
+                k = int(rng.integers(1, 4))
+                if rng.random() < 0.5:
+                    i += k                                   # deletion from the read
+                else:
+                    out.append("".join("ACGT"[x] for x in rng.integers(0, 4, k)))   # insertion
+                nxt = i + int(rng.integers(indel_every // 2, indel_every * 3 // 2))
+                continue
+            c = sq[i]
+            if rng.random() < p_sub:
+                c = "ACGT"[("ACGT".index(c) + int(rng.integers(1, 4))) % 4]
+            out.append(c); i += 1
+        return "".join(out)
+    reads = []
+    for k in range(90):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        L = int(rng.integers(800, 1501))
+        if len(c) <= L + 10:
+            c = max(contigs, key=len)
+        p = int(rng.integers(0, len(c) - L))
+        sq = c[p:p + L]
+        if k % 3 == 0:                                       # a diverged copy of another place inside the read
+            c2 = contigs[int(rng.integers(0, len(contigs)))]
+            l2 = int(rng.integers(120, 261))
+            if len(c2) > l2 + 10:
+                p2 = int(rng.integers(0, len(c2) - l2)); at = int(rng.integers(100, L - l2 - 100))
+                sq = sq[:at] + mutate(c2[p2:p2 + l2], 0.15, 0) + sq[at + l2:]
+        sq = mutate(sq, 0.04, 150)
+        if rng.random() < 0.5:
+            sq = "".join(comp[x] for x in reversed(sq))
+        reads.append(sq)
+    open(os.path.join(d, "long90.txt"), "w").write("".join(x + "\n" for x in reads))
+    summary = {}
+    with tempfile.TemporaryDirectory() as td:
+        tmp, ctmp, atmp = os.path.join(td, "o.bin"), os.path.join(td, "c.bin"), os.path.join(td, "a.bin")
+        r = run([os.path.join(REFBIN, "ref_dump"), os.path.join(g1, "ref"), os.path.join(d, "long90.txt"), tmp, "--chains", ctmp])
+        if r.returncode:
+            sys.exit(r.stderr)
+        np.savez_compressed(os.path.join(d, "long90.chains.npz"), **parse_chains(ctmp))
+        r = run([os.path.join(REFBIN, "ref_dump"), os.path.join(g1, "ref"), os.path.join(d, "long90.txt"), tmp, "--aln", atmp])
+        if r.returncode:
+            sys.exit(r.stderr)
+        a = parse_aln(atmp)
+        np.savez_compressed(os.path.join(d, "long90.aln.npz"), **a)
+        summary["long90"] = r.stderr.strip().splitlines()[-1]
+    zc = np.load(os.path.join(d, "long90.chains.npz"))
+    summary["seeds_in_chains_before_after"] = [int(zc["seed_rbeg"].size), int(a["cseed_rbeg"].size)]
+    summary["md5"] = {fn: md5(os.path.join(d, fn)) for fn in sorted(os.listdir(d)) if fn != "MANIFEST.json"}
+    json.dump(summary, open(os.path.join(d, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
@@ -370,6 +442,8 @@ def main():
         return make_config1()
     if len(sys.argv) > 1 and sys.argv[1] == "alt":
         return make_alt()
+    if len(sys.argv) > 1 and sys.argv[1] == "flt":
+        return make_flt()
     if len(sys.argv) > 1 and sys.argv[1] == "bsw":
         return make_bsw()
     if len(sys.argv) > 1 and sys.argv[1] == "bigref":

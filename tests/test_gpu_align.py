@@ -14,16 +14,19 @@ pytestmark = pytest.mark.gpu
 ALN = os.path.join(os.path.dirname(_data.GOLD), "aln1")
 
 
+FLT = os.path.join(os.path.dirname(_data.GOLD), "flt1")   # long reads (800-1500 bases): tests/golden/make_golden.py flt
+
+
 def _load(name):
-    z = np.load(os.path.join(ALN, name + ".aln.npz"))
-    rd_dir = ALN if name.startswith("indel") else _data.GOLD
+    z = np.load(os.path.join(FLT if name.startswith("long") else ALN, name + ".aln.npz"))
+    rd_dir = ALN if name.startswith("indel") else FLT if name.startswith("long") else _data.GOLD
     raw = open(os.path.join(rd_dir, name + ".txt"), "rb").read()
     reads = raw.split(b"\n")[:-1] if raw.endswith(b"\n") else raw.split(b"\n")
     bases, off = _data.pack_reads(reads)
     return z, bases, off
 
 
-@pytest.mark.parametrize("name", ["main100", "sorted150", "ragged", "repeat100", "indel150_400"])
+@pytest.mark.parametrize("name", ["main100", "sorted150", "ragged", "repeat100", "indel150_400", "long90"])
 def test_alignment_regions_are_the_references(name):
     import compseed_amd as ca
     z, bases, off = _load(name)
@@ -46,6 +49,28 @@ def test_alignment_regions_are_the_references(name):
     assert np.array_equal(g["frac_rep"].view(np.uint32), z["reg_frac_rep"].view(np.uint32))
     assert st["regions"] == g.size and st["purged"] == int(purged.sum()) and st["pairs"] >= st["regions"] // 2
     assert g.size > 4000 and purged.sum() > 1000
+
+
+@pytest.mark.parametrize("name", ["sorted150", "indel150_400", "long90"])
+def test_reads_to_regions_through_the_abi_equal_the_references(name):
+    """the library's whole side of comp_seed.cpp:2242-2374 from the reads: GPU seeding -> cs_chain_batch -> cs_chain_filter ->
+    cs_extend_chains; the regions are the reference's, field by field"""
+    import compseed_amd as ca
+    z, bases, off = _load(name)
+    ix = ca.Index.load(_data.PREFIX)
+    eng = ca.Engine(ix, 0)
+    res = eng.seed_batch(bases, off, ca.Params())
+    ch = ca.Chainer(_data.PREFIX)
+    c = ch.chain(res.mem_off, res.mems, res.seed_off, res.seeds, off, ca.ChainParams(), threads=2)
+    f = ch.filter(c["chain_off"], c["chains"], c["cseed_off"], c["cseeds"], bases, off, threads=2)
+    assert np.array_equal(f["chain_off"], z["chain_off"]) and np.array_equal(f["chains"]["pos"], z["chain_pos"]) and np.array_equal(f["cseed_score"], z["cseed_score"])
+    al = ca.Aligner(_data.PREFIX, 0)
+    got = al.extend_chains(f["chain_off"], f["chains"], f["cseed_off"], f["cseeds"], bases, off, cseed_score=f["cseed_score"])
+    g = got["regs"]
+    assert np.array_equal(got["reg_off"], z["reg_off"])
+    for fld in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "chain"):
+        assert np.array_equal(g[fld], z["reg_" + fld]), (name, fld)
+    al.close(); ch.close(); eng.close(); ix.close()
 
 
 def test_engine_chainer_aligner_end_to_end():
