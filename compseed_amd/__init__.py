@@ -7,9 +7,9 @@ Engine without the built library or without a GPU raises.
 """
 from . import binding  # noqa: F401
 from .binding import (CSError, Engine, EngineOptions, Index, Params, Result, Stats, lib_path, load_library, build_library,  # noqa: F401
-                      disable_mask, pinned_array, pack_reads, RefSeq, Reader, Chainer, ChainParams, FltParams, build_index_from_fasta, unpack_mems16, INTV_DT, SEED_DT, MEM16_DT,
+                      disable_mask, pinned_array, pack_reads, RefSeq, Reader, Chainer, ChainParams, FltParams, DedupParams, build_index_from_fasta, unpack_mems16, INTV_DT, SEED_DT, MEM16_DT,
                       Extender, ExtParams, EXT_PAIR_DT, EXT_RES_DT, packed_rbeg, Aligner, AlnParams, ALNREG_DT, CHAIN_DT)
 
 __all__ = ["CSError", "Engine", "EngineOptions", "Index", "Params", "Result", "Stats", "lib_path", "load_library", "build_library",
-           "disable_mask", "pinned_array", "pack_reads", "RefSeq", "Reader", "Chainer", "ChainParams", "FltParams", "build_index_from_fasta", "unpack_mems16", "INTV_DT", "SEED_DT", "MEM16_DT",
+           "disable_mask", "pinned_array", "pack_reads", "RefSeq", "Reader", "Chainer", "ChainParams", "FltParams", "DedupParams", "build_index_from_fasta", "unpack_mems16", "INTV_DT", "SEED_DT", "MEM16_DT",
            "Extender", "ExtParams", "EXT_PAIR_DT", "EXT_RES_DT", "packed_rbeg", "Aligner", "AlnParams", "ALNREG_DT", "CHAIN_DT"]

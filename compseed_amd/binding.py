@@ -19,7 +19,7 @@ SYMBOLS = ["cs_last_error", "cs_version", "cs_params_default", "cs_index_load", 
            "cs_engine_extend", "cs_engine_sa", "cs_engine_probe_random_lines", "cs_device_alloc", "cs_device_free", "cs_device_upload",
            "cs_device_download", "cs_device_sync", "cs_packed_seed_rbeg", "cs_engine_check_index",
            "cs_ext_params_default", "cs_extender_create", "cs_extender_destroy", "cs_extend_batch", "cs_extend_batch_device", "cs_extender_stats",
-           "cs_extender_upload", "cs_extend_batch_resident", "cs_aln_params_default", "cs_aligner_create", "cs_aligner_destroy", "cs_extend_chains", "cs_aligner_stats"]
+           "cs_extender_upload", "cs_extend_batch_resident", "cs_aln_params_default", "cs_aligner_create", "cs_aligner_destroy", "cs_extend_chains", "cs_dedup_params_default", "cs_dedup_regions", "cs_aligner_stats"]
 
 
 class CSError(RuntimeError):
@@ -96,6 +96,14 @@ class FltParams(C.Structure):
             if k not in dict(self._fields_):
                 raise TypeError("no such field: " + k)
             setattr(self, k, v)
+
+
+class DedupParams(C.Structure):
+    """cs_dedup_params_t; defaults = mem_opt_init (mapping/comp_seed.cpp:26-58)"""
+    _fields_ = [("max_chain_gap", C.c_int32), ("mask_level_redun", C.c_float)]
+
+    def __init__(self, max_chain_gap=10000, mask_level_redun=0.95):
+        super().__init__(max_chain_gap, mask_level_redun)
 
 
 class CChainResult(C.Structure):
@@ -337,6 +345,9 @@ def load_library():
     L.cs_aligner_destroy.restype = None
     L.cs_extend_chains.argtypes = [vp, C.POINTER(CChainResult), vp, vp, vp, C.POINTER(CAlnResult)]
     L.cs_aligner_stats.argtypes = [vp, C.POINTER(AlnStats)]
+    L.cs_dedup_params_default.argtypes = [C.POINTER(DedupParams)]
+    L.cs_dedup_params_default.restype = None
+    L.cs_dedup_regions.argtypes = [vp, C.POINTER(DedupParams), C.POINTER(CAlnResult), vp, vp, C.POINTER(CAlnResult), C.POINTER(vp)]
     _lib = L
     return L
 
@@ -828,6 +839,16 @@ class Aligner:
         out = CAlnResult()
         _check(self.L.cs_extend_chains(self.h, C.byref(cr), sc.ctypes.data if sc is not None and sc.size else None, bases.ctypes.data if bases.size else None, ro.ctypes.data, C.byref(out)))
         return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1), regs=_view(out.regs, ALNREG_DT, int(out.n_regs)))
+
+    def dedup_regions(self, reg_off, regs, bases, read_offsets, params=None):
+        """cs_dedup_regions (purged regions dropped, mem_sort_dedup_patch): regions as extend_chains returns them -> dict(reg_off, regs, n_comp), copies"""
+        params = params or DedupParams()
+        reg_off = np.ascontiguousarray(reg_off, dtype=np.uint64); regs = np.ascontiguousarray(regs, dtype=ALNREG_DT)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8); ro = np.ascontiguousarray(read_offsets, dtype=np.uint64)
+        cin = CAlnResult(reg_off.size - 1, regs.size, reg_off.ctypes.data, regs.ctypes.data if regs.size else None)
+        out = CAlnResult(); nc = C.c_void_p()
+        _check(self.L.cs_dedup_regions(self.h, C.byref(params), C.byref(cin), bases.ctypes.data if bases.size else None, ro.ctypes.data, C.byref(out), C.byref(nc)))
+        return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1), regs=_view(out.regs, ALNREG_DT, int(out.n_regs)), n_comp=_view(nc.value, "<i4", int(out.n_regs)))
 
     def stats(self):
         st = AlnStats()

@@ -24,6 +24,7 @@ struct cs_aligner {
 	cs_aln_params_t par{};
 	cs_extender_t *ext = nullptr;
 	std::vector<uint64_t> reg_off; std::vector<cs_alnreg_t> regs;
+	std::vector<uint64_t> dd_off; std::vector<cs_alnreg_t> dd_regs; std::vector<int32_t> dd_ncomp;   // cs_dedup_regions' result
 	cs_aln_stats_t st{};
 };
 
@@ -74,8 +75,10 @@ extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_pa
 	xp.o_del = o.o_del; xp.e_del = o.e_del; xp.o_ins = o.o_ins; xp.e_ins = o.e_ins; xp.zdrop = o.zdrop; xp.end_bonus = o.pen_clip5; xp.flags = 0;
 	// (the end bonus only enters the band limit, ksw.c:402-410; the reference builds one object per side, with pen_clip5 and pen_clip3,
 	// comp_seed.cpp:1702-1708: two extenders are kept when the two differ)
-	rc = cs_extender_create(device, &xp, &A->ext);
-	if (rc != CS_OK) { delete A; return rc; }
+	if (device >= 0) { // device -1: an aligner for the host-side passes only (cs_dedup_regions); cs_extend_chains then fails with CS_EDEVICE
+		rc = cs_extender_create(device, &xp, &A->ext);
+		if (rc != CS_OK) { delete A; return rc; }
+	}
 	*out = A;
 	return CS_OK;
 }
@@ -89,6 +92,7 @@ extern "C" void cs_aligner_destroy(cs_aligner_t *A)
 extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains, const int32_t *cseed_score, const uint8_t *bases,
                                 const uint64_t *read_offsets, cs_aln_result_t *out)
 {
+	if (A && !A->ext) return cs_fail_(CS_EDEVICE, "cs_extend_chains: this aligner was created without a device (device -1): the extension runs on the GPU only");
 	if (!A || !chains || !out || (chains->n_reads > 0 && (!read_offsets || !chains->chain_off)) || (chains->n_chains > 0 && (!chains->chains || !chains->cseed_off)) ||
 	    (chains->n_seeds > 0 && (!chains->cseeds || !bases)))
 		return cs_fail_(CS_EINVAL, "cs_extend_chains: bad argument");
@@ -322,6 +326,20 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 	A->st.purged += n_purged.load();
 	A->st.reads += (uint64_t)n; A->st.regions += A->regs.size();
 	out->n_reads = n; out->n_regs = A->regs.size(); out->reg_off = A->reg_off.data(); out->regs = A->regs.data();
+	return CS_OK;
+}
+
+extern "C" int cs_dedup_regions(cs_aligner_t *A, const cs_dedup_params_t *par, const cs_aln_result_t *regs, const uint8_t *bases, const uint64_t *read_offsets,
+                                cs_aln_result_t *out, const int32_t **n_comp)
+{
+	if (!A || !par || !regs || !out || (regs->n_reads > 0 && (!regs->reg_off || !read_offsets)) || (regs->n_regs > 0 && (!regs->regs || !bases))) return cs_fail_(CS_EINVAL, "cs_dedup_regions: bad argument");
+	if (regs->regs == A->dd_regs.data() && regs->n_regs) return cs_fail_(CS_EINVAL, "cs_dedup_regions: the input is this function's own previous output");
+	if (par->max_chain_gap < 0 || !(par->mask_level_redun > 0.f)) return cs_fail_(CS_EINVAL, "cs_dedup_regions: bad parameters");
+	const cs_aligner_core core = {&A->ref, &A->pac, &A->par};
+	const int rc = cs_dedup_regions_(core, par, regs, bases, read_offsets, A->dd_off, A->dd_regs, A->dd_ncomp);
+	if (rc != CS_OK) return rc;
+	out->n_reads = regs->n_reads; out->n_regs = A->dd_regs.size(); out->reg_off = A->dd_off.data(); out->regs = A->dd_regs.data();
+	if (n_comp) *n_comp = A->dd_ncomp.data();
 	return CS_OK;
 }
 

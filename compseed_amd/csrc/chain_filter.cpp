@@ -15,6 +15,7 @@
 // score is ksw_align2's (bwalib/ksw.c:343, 16-bit striped kernel :232-331), an affine-gap Smith-Waterman whose deletion state is
 // updated from H BEFORE the lazy-F correction across its eight query segments: restated as a scalar recurrence with exactly that rule.
 #include "cs_internal.hpp"
+#include "klib_sort.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -26,61 +27,6 @@ namespace {
 
 struct WRec { int32_t w, idx; };
 inline bool heavier(const WRec &a, const WRec &b) { return a.w > b.w; } // flt_lt (comp_seed.cpp:294): descending weight
-
-void insertion_pass(WRec *s, WRec *t) // (ksort.h:146-153)
-{
-	for (WRec *i = s + 1; i < t; ++i)
-		for (WRec *j = i; j > s && heavier(*j, *(j - 1)); --j) std::swap(*j, *(j - 1));
-}
-void comb_pass(size_t n, WRec *a) // (ksort.h:154-175)
-{
-	const double shrink = 1.2473309501039786540366528676643;
-	size_t gap = n; bool swapped;
-	do {
-		if (gap > 2) { gap = (size_t)((double)gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
-		swapped = false;
-		for (WRec *i = a; i < a + n - gap; ++i) if (heavier(i[gap], *i)) { std::swap(*i, i[gap]); swapped = true; }
-	} while (swapped || gap > 2);
-	if (gap != 1) insertion_pass(a, a + n);
-}
-void klib_introsort(size_t n, WRec *a) // (ksort.h:176-226)
-{
-	if (n < 1) return;
-	if (n == 2) { if (heavier(a[1], a[0])) std::swap(a[0], a[1]); return; }
-	int d = 2;
-	while ((1ul << d) < n) ++d;
-	struct Frame { WRec *lo, *hi; int depth; };
-	std::vector<Frame> stack; stack.reserve(sizeof(size_t) * (size_t)d + 2);
-	WRec *s = a, *t = a + (n - 1);
-	d <<= 1;
-	for (;;) {
-		if (s < t) {
-			if (--d == 0) { comb_pass((size_t)(t - s) + 1, s); t = s; continue; }
-			WRec *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
-			if (heavier(*k, *i)) { if (heavier(*k, *j)) k = j; }
-			else k = heavier(*j, *i) ? i : j;
-			const WRec pivot = *k;
-			if (k != t) std::swap(*k, *t);
-			for (;;) {
-				do ++i; while (heavier(*i, pivot));
-				do --j; while (i <= j && heavier(pivot, *j));
-				if (j <= i) break;
-				std::swap(*i, *j);
-			}
-			std::swap(*i, *t);
-			if (i - s > t - i) {
-				if (i - s > 16) stack.push_back({s, i - 1, d});
-				s = t - i > 16 ? i + 1 : t;
-			} else {
-				if (t - i > 16) stack.push_back({i + 1, t, d});
-				t = i - s > 16 ? i - 1 : s;
-			}
-		} else {
-			if (stack.empty()) { insertion_pass(a, a + n); return; }
-			s = stack.back().lo; t = stack.back().hi; d = stack.back().depth; stack.pop_back();
-		}
-	}
-}
 
 // bases covered by a chain's seeds, on the read and on the reference, whichever is less (mem_chain_weight, comp_seed.cpp:205-224)
 int chain_weight(const cs_seed_t *sd, int n)
@@ -155,7 +101,7 @@ void filter_range(const cs_chainer &C, const cs_flt_params_t &o, const cs_chain_
 		const int n = (int)srt.size();
 		order.clear();
 		if (n > 0) {
-			klib_introsort((size_t)n, srt.data());
+			cs_klib_introsort((size_t)n, srt.data(), heavier);
 			auto beg = [&](int i) { return (int)seeds_of(srt[(size_t)i].idx)[0].qbeg; };
 			auto end = [&](int i) { const cs_seed_t &s = seeds_of(srt[(size_t)i].idx)[nseeds_of(srt[(size_t)i].idx) - 1]; return (int)(s.qbeg + s.len); };
 			auto alt = [&](int i) { return in.chains[c0 + (uint64_t)srt[(size_t)i].idx].is_alt != 0; };

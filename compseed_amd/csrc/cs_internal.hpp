@@ -35,3 +35,8 @@ struct cs_chainer {
 
 // the reads of a part as 16-byte records of 32 bases, made on host threads (host_pack.cpp; bit-identical to pack_reads_kernel's)
 void cs_pack_reads_host_(const uint8_t *bases, const uint64_t *offsets, int64_t r0, int64_t n, int64_t lo, int64_t hi, void *rec_out, int threads, int force_scalar);
+
+// the part of an aligner the host-side region passes need (dedup.cpp: mem_sort_dedup_patch)
+struct cs_aligner_core { const cs_refseq_view *ref; const std::vector<uint8_t> *pac; const cs_aln_params_t *par; };
+int cs_dedup_regions_(const cs_aligner_core &A, const cs_dedup_params_t *par, const cs_aln_result_t *regs, const uint8_t *bases, const uint64_t *read_offsets,
+                      std::vector<uint64_t> &out_off, std::vector<cs_alnreg_t> &out_regs, std::vector<int32_t> &out_ncomp);

@@ -371,10 +371,20 @@ typedef struct { int64_t n_reads; uint64_t n_regs; const uint64_t *reg_off; cons
 typedef struct { uint64_t reads, regions, pairs, retries, purged, launches; } cs_aln_stats_t;   /* pairs = extensions run incl. retries */
 typedef struct cs_aligner cs_aligner_t;
 void cs_aln_params_default(cs_aln_params_t *p);
-int  cs_aligner_create(const char *prefix, int device, const cs_aln_params_t *par /* NULL: defaults */, cs_aligner_t **out);
+int  cs_aligner_create(const char *prefix, int device /* -1: host-side passes only (cs_dedup_regions), no GPU needed */, const cs_aln_params_t *par /* NULL: defaults */, cs_aligner_t **out);
 void cs_aligner_destroy(cs_aligner_t *a);
 int  cs_extend_chains(cs_aligner_t *a, const cs_chain_result_t *chains, const int32_t *cseed_score, const uint8_t *bases,
                       const uint64_t *read_offsets, cs_aln_result_t *out);
+/* The pass behind the extension stage (comp_seed.cpp:2385-2395), host code: regions marked by the purge (qe <= qb) are dropped and
+ * mem_sort_dedup_patch (comp_seed.cpp:629-687) runs over each read's rest -- of two regions that overlap by more than mask_level_redun on
+ * read and reference the lower-scoring one goes; colinear neighbours close to one diagonal are merged when a banded global alignment over
+ * both (bwa_gen_cigar2 / ksw_global2) scores at least 0.9 of what they promise; the survivors come sorted by score.  `regs`: cs_extend_chains'
+ * result (or the caller's regions in that form); `n_comp`: per surviving region, mem_alnreg_t.n_comp (1, more after merges; 0 for a read's only region, which the reference's function does not touch).  `chain` of a
+ * merged region is that of its later part.  The result belongs to the aligner and stays valid until its next cs_dedup_regions. */
+typedef struct { int32_t max_chain_gap; float mask_level_redun; } cs_dedup_params_t;   /* mem_opt_t: max_chain_gap 10000, mask_level_redun 0.95 */
+void cs_dedup_params_default(cs_dedup_params_t *p);
+int  cs_dedup_regions(cs_aligner_t *a, const cs_dedup_params_t *par, const cs_aln_result_t *regs, const uint8_t *bases, const uint64_t *read_offsets,
+                      cs_aln_result_t *out, const int32_t **n_comp);
 int  cs_aligner_stats(const cs_aligner_t *a, cs_aln_stats_t *st);
 
 /* ---- the result of the LAST device-variant call, without moving it: an order-sensitive 64-bit digest per array

@@ -10,6 +10,8 @@
 // record = 17 x int32 { kind (8 / 16 / 1 = scalar), w, zdrop, end_bonus, o_del, e_del, o_ins, e_ins, qlen, tlen, h0,
 //                       score, qle, tle, gtle, gscore, max_off } + qlen query bytes + tlen target bytes (codes 0..4)
 // file   = "CSBSW01\0" + 25 bytes of the scoring matrix of the first object constructed + records
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,6 +54,27 @@ void record(const void *self, int kind, const SeqPair *p, int n, const uint8_t *
 	}
 	fflush(f);
 }
+// $CS_BSW_TIME set: the time the reference's real functions take is summed over all calls and threads and printed at exit --
+// "[bswtrace] pairs=<n> thread_seconds=<s> cells=<qlen x tlen summed>" -- the CPU baseline of tools/extend_bench.py (the reference's own
+// vectorised extension code on the GPU box's host cores).
+std::atomic<long long> t_ns{0}, t_pairs{0}, t_cells{0};
+bool timing() { static const bool on = getenv("CS_BSW_TIME") != nullptr; return on; }
+void report()
+{
+	fprintf(stderr, "[bswtrace] pairs=%lld thread_seconds=%.6f cells=%lld\n", t_pairs.load(), (double)t_ns.load() * 1e-9, t_cells.load());
+}
+void arm_report() { static std::once_flag once; std::call_once(once, [] { atexit(report); }); }
+template <class F> void timed(const SeqPair *p, int n, F &&call)
+{
+	if (!timing()) { call(); return; }
+	arm_report();
+	const auto t0 = std::chrono::steady_clock::now();
+	call();
+	t_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+	long long cells = 0;
+	for (int i = 0; i < n; ++i) cells += (long long)p[i].len1 * p[i].len2;
+	t_pairs += n; t_cells += cells;
+}
 } // namespace
 
 // the real functions (the reference's code) and the wrappers the linker routes the reference's calls to
@@ -72,17 +95,17 @@ void wrap_ctor(void *self, int o_del, int e_del, int o_ins, int e_ins, int zdrop
 
 void wrap_gs8(void *self, SeqPair *p, uint8_t *ref, uint8_t *qer, int32_t n, uint16_t nt, int32_t w)
 {
-	real_gs8(self, p, ref, qer, n, nt, w);
+	timed(p, n, [&] { real_gs8(self, p, ref, qer, n, nt, w); });
 	record(self, 8, p, n, ref, qer, w);
 }
 void wrap_gs16(void *self, SeqPair *p, uint8_t *ref, uint8_t *qer, int32_t n, uint16_t nt, int32_t w)
 {
-	real_gs16(self, p, ref, qer, n, nt, w);
+	timed(p, n, [&] { real_gs16(self, p, ref, qer, n, nt, w); });
 	record(self, 16, p, n, ref, qer, w);
 }
 void wrap_scal(void *self, SeqPair *p, uint8_t *ref, uint8_t *qer, int n, int nt, int32_t w)
 {
-	real_scal(self, p, ref, qer, n, nt, w);
+	timed(p, n, [&] { real_scal(self, p, ref, qer, n, nt, w); });
 	record(self, 1, p, n, ref, qer, w);
 }
 void wrap_ctor(void *self, int o_del, int e_del, int o_ins, int e_ins, int zdrop, int end_bonus, const int8_t *mat, int8_t a, int8_t b, int nt)

@@ -59,6 +59,7 @@ typedef struct {
 } mem_cache;
 void mem_chain2aln_across_reads_V2(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, bseq1_t *seq_, int nseq, mem_chain_v *chain_ar,
                                    mem_alnreg_v *av_v, mem_cache *mmc, int tid);
+int mem_sort_dedup_patch(const mem_opt_t *opt, const bntseq_t *bns, const uint8_t *pac, uint8_t *query, int n, mem_alnreg_t *a); // (comp_seed.cpp:629)
 
 static bool by_info(const bwtintv_t &a, const bwtintv_t &b) { return a.info < b.info; }
 
@@ -250,7 +251,7 @@ int main(int argc, char **argv)
 	}
 	mem_opt_t *opt = mem_opt_init();
 	int batch = BATCH_SIZE;
-	const char *prim_fn = 0, *chain_fn = 0, *aln_fn = 0; long prim_n = 0; uint64_t prim_seed = 1; int time_threads = 0;
+	const char *prim_fn = 0, *chain_fn = 0, *aln_fn = 0, *dedup_fn = 0; long prim_n = 0; uint64_t prim_seed = 1; int time_threads = 0;
 	for (int i = 4; i < argc; i++) {
 		std::string a = argv[i];
 		if (a == "-k") opt->min_seed_len = atoi(argv[++i]);
@@ -262,6 +263,7 @@ int main(int argc, char **argv)
 		else if (a == "--prim") { prim_fn = argv[++i]; prim_n = atol(argv[++i]); prim_seed = strtoull(argv[++i], 0, 10); }
 		else if (a == "--chains") chain_fn = argv[++i];
 		else if (a == "--aln") aln_fn = argv[++i];
+		else if (a == "--dedup") dedup_fn = argv[++i];   // with --aln: also the regions mem_sort_dedup_patch leaves (comp_seed.cpp:2385-2395)
 		else if (a == "--time") time_threads = atoi(argv[++i]);
 		else { fprintf(stderr, "unknown option %s\n", argv[i]); return 1; }
 	}
@@ -396,6 +398,7 @@ int main(int argc, char **argv)
 		struct reg_out_t { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0; float frac_rep; int32_t chain; };
 		std::vector<uint64_t> chain_off(n + 1, 0), reg_off(n + 1, 0);
 		std::vector<chain_out_t> chains; std::vector<cseed_out_t> cseeds; std::vector<reg_out_t> regs;
+		std::vector<uint64_t> ddp_off(n + 1, 0); std::vector<reg_out_t> ddp; // --dedup: same record, `chain` holds n_comp
 		mem_cache *mmc = (mem_cache *)calloc(1, sizeof(mem_cache));
 		const int64_t wsize = (int64_t)BATCH_SIZE * SEEDS_PER_READ;
 		mmc->seqBufLeftRef[0] = (uint8_t *)_mm_malloc(wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64); mmc->seqBufRightRef[0] = (uint8_t *)_mm_malloc(wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64);
@@ -443,6 +446,18 @@ int main(int argc, char **argv)
 					regs.push_back(o);
 				}
 				reg_off[b0 + r + 1] = regs.size();
+				if (dedup_fn) { // what seed_and_extend does with a read's regions next (comp_seed.cpp:2385-2395): drop the purged ones, then mem_sort_dedup_patch
+					mem_alnreg_v &rg = reg_ar[r];
+					int m = 0;
+					for (size_t i = 0; i < rg.n; ++i) if (rg.a[i].qe > rg.a[i].qb) { if (m != (int)i) rg.a[m++] = rg.a[i]; else ++m; }
+					m = mem_sort_dedup_patch(opt, idx->bns, idx->pac, codes[r].data(), m, rg.a);
+					for (int i = 0; i < m; ++i) {
+						const mem_alnreg_t &a = rg.a[i];
+						reg_out_t o = {a.rb, a.re, a.qb, a.qe, a.rid, a.score, a.truesc, a.w, a.seedcov, a.seedlen0, a.frac_rep, a.n_comp};
+						ddp.push_back(o);
+					}
+					ddp_off[b0 + r + 1] = ddp.size();
+				}
 				for (size_t c = 0; c < chain_ar[r].n; c++) free(chain_ar[r].a[c].seeds);
 				free(chain_ar[r].a); free(reg_ar[r].a);
 			}
@@ -454,6 +469,14 @@ int main(int argc, char **argv)
 		fwrite(chain_off.data(), 8, n + 1, fa); fwrite(chains.data(), sizeof(chain_out_t), chains.size(), fa); fwrite(cseeds.data(), sizeof(cseed_out_t), cseeds.size(), fa);
 		fwrite(reg_off.data(), 8, n + 1, fa); fwrite(regs.data(), sizeof(reg_out_t), regs.size(), fa);
 		fclose(fa);
+		if (dedup_fn) { // file: "CSDDP01\0"; u64 n_reads, n_regs; u64 reg_off[n+1]; reg records (chain = n_comp)
+			FILE *fd = fopen(dedup_fn, "wb");
+			if (!fd) { perror(dedup_fn); return 1; }
+			uint64_t h2[2] = {n, ddp.size()};
+			fwrite("CSDDP01", 1, 8, fd); fwrite(h2, 8, 2, fd); fwrite(ddp_off.data(), 8, n + 1, fd); fwrite(ddp.data(), sizeof(reg_out_t), ddp.size(), fd);
+			fclose(fd);
+			fprintf(stderr, "[ref_dump] dedup: regions=%zu\n", ddp.size());
+		}
 		size_t purged = 0;
 		for (const auto &g : regs) purged += g.qb == -1 && g.qe == -1;
 		fprintf(stderr, "[ref_dump] extension: chains=%zu seeds=%zu regions=%zu (purged %zu)\n", chains.size(), cseeds.size(), regs.size(), purged);

@@ -17,6 +17,7 @@ What is produced (all data, no reference source text):
                                      recorded from its own run, and known answers of its scalar ksw_extend2
   aln1/                              `make_golden.py aln`: the reference's extension stage (mem_chain2aln_across_reads_V2): filtered chains in, alignment regions out
   c2/config2.json                    `make_golden.py bigref`: md5 of bwaidx's five files for a 64 Mbp genome (its bwt_bwtgen2 branch)
+  ddp1/                              `make_golden.py ddp`: the regions mem_sort_dedup_patch leaves, for aln1's and flt1's read sets and one with long gaps (regions merged by the patch)
   flt1/                              `make_golden.py flt`: 90 long reads (800-1500 bases): the reference's unfiltered chains, and what its two chain filters leave (+ regions)
   alt1/                              `make_golden.py alt`: main100's chains with a <prefix>.alt file naming chr2 (is_alt of the chains)
   c1/config1.json                    BASELINE configs[0] (E. coli-size genome, 100 k x 100 bp reads): the reference's counters and
@@ -435,6 +436,65 @@ def make_flt():
     print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
 
 
+def parse_ddp(path):
+    raw = open(path, "rb").read()
+    assert raw[:7] == b"CSDDP01"
+    n, n_regs = [int(x) for x in np.frombuffer(raw, dtype="<u8", count=2, offset=8)]
+    off = 24
+    reg_off = np.frombuffer(raw, dtype="<u8", count=n + 1, offset=off); off += 8 * (n + 1)
+    rg = np.frombuffer(raw, dtype=np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"), ("truesc", "<i4"), ("w", "<i4"),
+                                             ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"), ("n_comp", "<i4")]), count=n_regs, offset=off)
+    out = dict(reg_off=reg_off.copy())
+    for k in rg.dtype.names:
+        out["reg_" + k] = rg[k].copy()
+    return out
+
+
+def make_ddp():
+    """ddp1/: what the reference does with a read's alignment regions next (comp_seed.cpp:2385-2395): the purged ones dropped, then
+    mem_sort_dedup_patch (comp_seed.cpp:629: sorted by end position, redundant regions removed, colinear neighbours merged when a banded
+    global alignment over both scores well, sorted by score, identical ones removed).  Read sets: aln1's five, flt1's long reads, and
+    gap3k.txt: 120 reads of 3000-3600 bases with a 103-140-base deletion or insertion in the middle -- two regions per read that the
+    extension does not join (the gap costs more than Z-drop allows) and the patch does (small against the read's length).  For gap3k also the .aln dump (the input of the stage)."""
+    import gzip, tempfile
+    d = os.path.join(HERE, "ddp1"); os.makedirs(d, exist_ok=True)
+    g1 = os.path.join(HERE, "g1")
+    fa = gzip.open(os.path.join(g1, "ref.fa.gz")).read().decode().split(">")[1:]
+    contigs = ["".join(c.split("\n")[1:]).upper().replace("N", "A") for c in fa]
+    rng = np.random.default_rng(20261005)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for k in range(120):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        L = int(rng.integers(3000, 3601)); g = int(rng.integers(103, 141)); h = L // 2
+        p = int(rng.integers(0, len(c) - L - g - 10))
+        if k % 2 == 0:                                       # deletion from the read: beyond what Z-drop lets an extension cross, small against the read
+            sq = c[p:p + h] + c[p + h + g:p + L + g]
+        else:                                                # insertion of unrelated bases
+            sq = c[p:p + h] + "".join("ACGT"[x] for x in rng.integers(0, 4, g)) + c[p + h:p + L]
+        sq = "".join(x if rng.random() > 0.005 else "ACGT"[("ACGT".index(x) + 1) % 4] for x in sq)
+        if rng.random() < 0.5:
+            sq = "".join(comp[x] for x in reversed(sq))
+        reads.append(sq)
+    open(os.path.join(d, "gap3k.txt"), "w").write("".join(x + "\n" for x in reads))
+    summary = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, rd_dir in (("main100", g1), ("sorted150", g1), ("ragged", g1), ("repeat100", g1), ("indel150_400", os.path.join(HERE, "aln1")),
+                             ("long90", os.path.join(HERE, "flt1")), ("gap3k", d)):
+            tmp, atmp, dtmp = os.path.join(td, "o.bin"), os.path.join(td, "a.bin"), os.path.join(td, "d.bin")
+            r = run([os.path.join(REFBIN, "ref_dump"), os.path.join(g1, "ref"), os.path.join(rd_dir, name + ".txt"), tmp, "--aln", atmp, "--dedup", dtmp])
+            if r.returncode:
+                sys.exit(r.stderr)
+            z = parse_ddp(dtmp)
+            np.savez_compressed(os.path.join(d, name + ".ddp.npz"), **z)
+            if name == "gap3k":
+                np.savez_compressed(os.path.join(d, name + ".aln.npz"), **parse_aln(atmp))
+            summary[name] = {"regions": int(z["reg_rb"].size), "merged": int((z["reg_n_comp"] > 1).sum())}
+    summary["md5"] = {fn: md5(os.path.join(d, fn)) for fn in sorted(os.listdir(d)) if fn != "MANIFEST.json"}
+    json.dump(summary, open(os.path.join(d, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in summary.items() if k != "md5"}, indent=1))
+
+
 def main():
     if not os.path.exists(os.path.join(REFBIN, "ref_dump")):
         sys.exit("build the reference harness first: make -C oracle ref")
@@ -444,6 +504,8 @@ def main():
         return make_alt()
     if len(sys.argv) > 1 and sys.argv[1] == "flt":
         return make_flt()
+    if len(sys.argv) > 1 and sys.argv[1] == "ddp":
+        return make_ddp()
     if len(sys.argv) > 1 and sys.argv[1] == "bsw":
         return make_bsw()
     if len(sys.argv) > 1 and sys.argv[1] == "bigref":

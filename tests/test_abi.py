@@ -93,7 +93,7 @@ def test_ctypes_structs_match_the_header(lib, tmp_path):
     import compseed_amd.binding as b
     structs = {"cs_index_view_t": b.IndexView, "cs_params_t": b.Params, "cs_result_t": b.CResult, "cs_stats_t": b.Stats,
                "cs_engine_options_t": b.EngineOptions, "cs_traffic_t": b.Traffic, "cs_digest_t": b.Digest, "cs_packed_result_t": b.CPacked, "cs_ext_params_t": b.ExtParams, "cs_ext_stats_t": b.ExtStats,
-               "cs_index_check_t": b.IndexCheck, "cs_flt_params_t": b.FltParams, "cs_aln_params_t": b.AlnParams, "cs_aln_result_t": b.CAlnResult, "cs_aln_stats_t": b.AlnStats}
+               "cs_index_check_t": b.IndexCheck, "cs_flt_params_t": b.FltParams, "cs_dedup_params_t": b.DedupParams, "cs_aln_params_t": b.AlnParams, "cs_aln_result_t": b.CAlnResult, "cs_aln_stats_t": b.AlnStats}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "compseed_amd.h"', 'int main(void) {']
     for cname, st in structs.items():
         src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

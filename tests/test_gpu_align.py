@@ -17,16 +17,19 @@ ALN = os.path.join(os.path.dirname(_data.GOLD), "aln1")
 FLT = os.path.join(os.path.dirname(_data.GOLD), "flt1")   # long reads (800-1500 bases): tests/golden/make_golden.py flt
 
 
+DDP = os.path.join(os.path.dirname(_data.GOLD), "ddp1")   # regions after mem_sort_dedup_patch; gap3k: 3-kb reads with a gap in the middle (make_golden.py ddp)
+
+
 def _load(name):
-    z = np.load(os.path.join(FLT if name.startswith("long") else ALN, name + ".aln.npz"))
-    rd_dir = ALN if name.startswith("indel") else FLT if name.startswith("long") else _data.GOLD
+    z = np.load(os.path.join(FLT if name.startswith("long") else DDP if name.startswith("gap") else ALN, name + ".aln.npz"))
+    rd_dir = ALN if name.startswith("indel") else FLT if name.startswith("long") else DDP if name.startswith("gap") else _data.GOLD
     raw = open(os.path.join(rd_dir, name + ".txt"), "rb").read()
     reads = raw.split(b"\n")[:-1] if raw.endswith(b"\n") else raw.split(b"\n")
     bases, off = _data.pack_reads(reads)
     return z, bases, off
 
 
-@pytest.mark.parametrize("name", ["main100", "sorted150", "ragged", "repeat100", "indel150_400", "long90"])
+@pytest.mark.parametrize("name", ["main100", "sorted150", "ragged", "repeat100", "indel150_400", "long90", "gap3k"])
 def test_alignment_regions_are_the_references(name):
     import compseed_amd as ca
     z, bases, off = _load(name)
@@ -51,10 +54,11 @@ def test_alignment_regions_are_the_references(name):
     assert g.size > 4000 and purged.sum() > 1000
 
 
-@pytest.mark.parametrize("name", ["sorted150", "indel150_400", "long90"])
+@pytest.mark.parametrize("name", ["sorted150", "indel150_400", "long90", "gap3k"])
 def test_reads_to_regions_through_the_abi_equal_the_references(name):
-    """the library's whole side of comp_seed.cpp:2242-2374 from the reads: GPU seeding -> cs_chain_batch -> cs_chain_filter ->
-    cs_extend_chains; the regions are the reference's, field by field"""
+    """the library's whole side of comp_seed.cpp:2242-2395 from the reads: GPU seeding -> cs_chain_batch -> cs_chain_filter ->
+    cs_extend_chains -> cs_dedup_regions; the regions are the reference's, field by field, after the extension stage and after
+    mem_sort_dedup_patch"""
     import compseed_amd as ca
     z, bases, off = _load(name)
     ix = ca.Index.load(_data.PREFIX)
@@ -70,6 +74,11 @@ def test_reads_to_regions_through_the_abi_equal_the_references(name):
     assert np.array_equal(got["reg_off"], z["reg_off"])
     for fld in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "chain"):
         assert np.array_equal(g[fld], z["reg_" + fld]), (name, fld)
+    zd = np.load(os.path.join(DDP, name + ".ddp.npz"))
+    dd = al.dedup_regions(got["reg_off"], g, bases, off)
+    assert np.array_equal(dd["reg_off"], zd["reg_off"]) and np.array_equal(dd["n_comp"], zd["reg_n_comp"])
+    for fld in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0"):
+        assert np.array_equal(dd["regs"][fld], zd["reg_" + fld]), (name, fld)
     al.close(); ch.close(); eng.close(); ix.close()
 
 

@@ -103,6 +103,25 @@ def run(n_pairs=2_000_000, steps=5, check=20000, cpu_pairs=200000, cpu_threads=1
         _oracle.bsw_extend(fx, threads=cpu_threads)
         dt = time.perf_counter() - t0
         out["cpu_port"] = {"pairs_per_s": k / dt, "threads": cpu_threads, "kind": "port", "sample": "first %d pairs, oracle/cs_bsw_oracle.c (scalar ksw_extend2 restated), %.1f s" % (k, dt)}
+    # the REAL reference's extension code (its vectorised getScores8 / getScores16 and the scalar wrapper, untouched) timed inside the
+    # reference's own program on the box's host cores: oracle/_ref/CompSeed.bswtrace with $CS_BSW_TIME sums the time of those calls
+    # over all threads (oracle/ref_bsw_trace.cpp); reads = tests/golden/bsw1/indel150.txt against the golden reference
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "CompSeed.bswtrace")
+    gold = os.path.join(ROOT, "tests", "golden")
+    if cpu_pairs and os.path.exists(ref_bin) and os.path.exists(os.path.join(gold, "g1", "ref.bwt")):
+        import re, subprocess
+        try:
+            env = dict(os.environ, CS_BSW_TIME="1"); env.pop("CS_BSW_TRACE", None)
+            r = subprocess.run([ref_bin, "-t", str(cpu_threads), os.path.join(gold, "g1", "ref"), os.path.join(gold, "bsw1", "indel150.txt")], env=env, cwd="/tmp",
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=120)
+            m = re.search(r"\[bswtrace\] pairs=(\d+) thread_seconds=([0-9.]+) cells=(\d+)", r.stderr)
+            if m:
+                pairs, ts, cells = int(m.group(1)), float(m.group(2)), int(m.group(3))
+                out["cpu_reference"] = {"pairs_per_thread_second": pairs / ts, "threads": cpu_threads, "pairs_per_s_all_threads": pairs / ts * cpu_threads, "kind": "reference",
+                                        "rect_cells_per_thread_second": cells / ts,
+                                        "sample": "%d extensions the reference ran on 1200 reads with indels (w and 2w tries), its own AVX2 code, time summed inside its calls over %d threads" % (pairs, cpu_threads)}
+        except Exception as ex:  # noqa: BLE001
+            out["cpu_reference_error"] = repr(ex)
     x.close()
     return out
 
