@@ -27,6 +27,7 @@
 #include <string>
 
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #define HIP_TRYX(expr)                                                                              \
 	do {                                                                                            \
@@ -367,6 +368,128 @@ __global__ __launch_bounds__(256, 8) void extend16_kernel(const ExtArgs A)
 	if (lane == 0 && A.stat) { atomicAdd(A.stat, my_cells); atomicAdd(A.stat + 1, my_rows); }
 }
 
+// ---- one pair per LANE (the default for short queries).  The kernels above spread ONE extension over a wave, which costs two max-scans,
+// three ballots and the band bookkeeping per 64-column chunk and leaves the lanes beyond the band idle: ~2 wave instructions per DP
+// cell of a 150-bp read's extension.  Here every lane runs ksw_extend2 (bwalib/ksw.c:380-479) for a pair of its own, cell by cell, the
+// way the reference's vectorised code runs one pair per SIMD lane (mapping/bandedSWA.cpp): no scans, no ballots, ~28 lane instructions
+// per cell.  What it needs instead: pairs of similar shape in a wave (the caller sorts them by query-length class and target length:
+// a wave takes as many rows as its longest target and as many columns per row as its widest band), and the two score arrays of every
+// lane in LDS -- H and E of a column packed into one dword (scores of this class are below 2^15), the lanes interleaved so that a
+// wave's access to "its column" never conflicts: (qmax + 2) x 256 bytes per wave, plus the query bytes.  Pairs outside the class
+// (longer queries, scores that may reach 2^15, the scalar scoring rule) are left to extend_kernel.
+constexpr int LANES_QCLASS[4] = {48, 80, 112, 160};                                     // query-length classes: one launch (and LDS size) each
+__device__ __host__ __forceinline__ int lanes_class_of(int qlen) { return qlen <= 48 ? 0 : qlen <= 80 ? 1 : qlen <= 112 ? 2 : qlen <= 160 ? 3 : 4; }
+
+// sort key of a pair for the lane kernel: class | target length | query length; 0xffffffff = not for the lane kernel (its result's score
+// is set to DECLINED so that extend_kernel takes it)
+__global__ void lanes_keys_kernel(const ExtArgs A, uint32_t *keys, uint32_t *idx, unsigned long long *class_cnt)
+{
+	__shared__ unsigned int cnt[4];                                        // (one atomic per block and class on the global counters: 2 M lanes on four words took 12 ms)
+	if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+	__syncthreads();
+	for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.n; p += (int64_t)gridDim.x * blockDim.x) {
+		const cs_ext_pair_t pr = A.pairs[p];
+		const bool ok = pr.qlen >= 1 && pr.tlen >= 0 && pr.tlen < 32768 && pr.q_off <= A.q_bytes && (uint64_t)pr.qlen <= A.q_bytes - pr.q_off && pr.t_off <= A.t_bytes &&
+		                (uint64_t)pr.tlen <= A.t_bytes - pr.t_off && pr.h0 >= 0;
+		const int cls = ok ? lanes_class_of(pr.qlen) : 4;
+		// every score of the extension stays below h0 + qlen x match: it has to fit 15 bits (and the reference's vectorised scoring rule applies)
+		const bool fits = cls < 4 && (int64_t)pr.h0 + (int64_t)pr.qlen * A.P.best < 32000;
+		if (fits) keys[p] = (uint32_t)cls << 28 | (uint32_t)pr.tlen << 12 | (uint32_t)pr.qlen;
+		else { keys[p] = 0xffffffffu; A.out[p].score = DECLINED; }
+		idx[p] = (uint32_t)p;
+		for (int c = 0; c < 4; ++c) { // (the lanes of a wave that are in this iteration, counted per class by one of them)
+			const unsigned long long mk = __ballot(fits && cls == c);
+			if (mk && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) atomicAdd(&cnt[c], (unsigned)__builtin_popcountll(mk));
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(class_cnt + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const uint32_t *order, int64_t first, int64_t count, int qmax)
+{
+	extern __shared__ uint32_t lsm[];
+	const int lane = threadIdx.x;
+	uint32_t *eh = lsm + lane;                                           // column j of this lane: eh[j * 64] = H | E << 16
+	uint8_t *qs = reinterpret_cast<uint8_t *>(lsm + (size_t)(qmax + 2) * 64) + lane; // query base j of this lane: qs[j * 64]
+	const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+	const bool have = k < count;
+	const int64_t p = have ? (int64_t)order[first + k] : 0;
+	const cs_ext_pair_t pr = have ? A.pairs[p] : cs_ext_pair_t{0, 0, 1, 0, 0, 0};
+	const ExtParams &P = A.P;
+	const int qlen = pr.qlen, tlen = have ? pr.tlen : 0, h0 = pr.h0;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_ins = P.e_ins, e_del = P.e_del;
+	const uint8_t *qg = A.qbuf + pr.q_off, *tg = A.tbuf + pr.t_off;
+	// row "-1" (ksw.c:398-400) and the query
+	if (have) {
+		const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
+		for (int j = 0; j <= qlen + 1; ++j) eh[j * 64] = (uint32_t)(j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0);
+		for (int j = 0; j < qlen; ++j) qs[j * 64] = qg[j];
+	}
+	int w = A.w;
+	{ // the band cannot usefully be wider than the longest gap the best possible score pays for (ksw.c:402-410)
+		int lim = (int)((double)(qlen * P.best + P.end_bonus - P.o_ins) / (double)e_ins + 1.);
+		lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+		lim = (int)((double)(qlen * P.best + P.end_bonus - P.o_del) / (double)e_del + 1.);
+		lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+	}
+	int top = h0, top_i = -1, top_j = -1, g_best = -1, g_row = -1, off = 0, beg = 0, end = qlen;
+	unsigned long long my_cells = 0, my_rows = 0;
+	int tnext = tlen > 0 ? (int)tg[0] : 4;
+	for (int i = 0; i < tlen; ++i) {
+		const int ti = tnext;
+		if (i + 1 < tlen) tnext = (int)tg[i + 1];
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1 = beg == 0 ? imax(h0 - (P.o_del + e_del * (i + 1)), 0) : 0;   // H(i, beg - 1) (ksw.c:419-423)
+		int f = 0, best = 0;                                                  // best = row maximum << 16 | its LAST column (ksw.c:440-441): one max per cell
+		const int s_eq = ti == 4 ? -1 : P.match, s_ne = ti == 4 ? -1 : P.mismatch;
+		uint32_t cell_n = eh[beg * 64]; int q_n = (int)qs[beg * 64];         // (column j + 1 is fetched while column j is computed: a lane has no neighbours to hide LDS latency behind)
+		for (int j = beg; j < end; ++j) {
+			const uint32_t cell = cell_n; const int qj = q_n;
+			cell_n = eh[(j + 1) * 64]; q_n = (int)qs[(j + 1) * 64];
+			int M = (int)(cell & 0xffffu), e = (int)(cell >> 16);
+			const int sc = qj == 4 ? -1 : (qj == ti ? s_eq : s_ne);
+			M = M != 0 ? M + sc : 0;                                        // a path may not restart from a zero cell (ksw.c:436)
+			const int h = imax(imax(M, e), f);
+			e = imax(e - e_del, imax(M - oe_del, 0));
+			eh[j * 64] = (uint32_t)h1 | (uint32_t)e << 16;                  // H(i, j-1): the diagonal of column j in the next row; E(i+1, j)
+			h1 = h;
+			best = imax(best, h << 16 | j);
+			f = imax(f - e_ins, imax(M - oe_ins, 0));
+		}
+		const int m = best >> 16, mj = best & 0xffff;
+		eh[end * 64] = (uint32_t)h1;
+		my_cells += (unsigned)(end > beg ? end - beg : 0); ++my_rows;
+		if ((beg < end ? end : beg) == qlen) { // the row reached the end of the query (ksw.c:452-455)
+			if (!(g_best > h1)) g_row = i;
+			g_best = imax(g_best, h1);
+		}
+		if (m == 0) break;
+		if (m > top) {
+			top = m; top_i = i; top_j = mj;
+			const int d = mj - i; off = imax(off, d < 0 ? -d : d);
+		} else if (P.zdrop > 0) { // Z-drop with the diagonal shift priced as a gap extension (ksw.c:461-467)
+			const int di = i - top_i, dj = mj - top_j;
+			if (di > dj) { if (top - m - (di - dj) * e_del > P.zdrop) break; }
+			else if (top - m - (dj - di) * e_ins > P.zdrop) break;
+		}
+		// the live columns (ksw.c:470-473 look at the arrays as this row leaves them): the zero cells at either edge are usually none or one,
+		// so two short scans are cheaper than keeping track of them in every cell
+		int nbeg = beg;
+		while (nbeg < end && eh[nbeg * 64] == 0) ++nbeg;
+		int jz = end;
+		if (h1 == 0) { jz = end - 1; while (jz >= nbeg && eh[jz * 64] == 0) --jz; }
+		beg = nbeg; end = jz + 2 < qlen ? jz + 2 : qlen;
+	}
+	if (have) { cs_ext_result_t r = {top, top_j + 1, top_i + 1, g_row + 1, g_best, off}; A.out[p] = r; }
+	if (A.stat) {
+		for (int o = 32; o > 0; o >>= 1) { my_cells += __shfl_xor(my_cells, o); my_rows += __shfl_xor(my_rows, o); }
+		if (lane == 0) { atomicAdd(A.stat, my_cells); atomicAdd(A.stat + 1, my_rows); }
+	}
+}
+
 __global__ void max_qlen_kernel(const cs_ext_pair_t *pairs, int64_t n, unsigned long long *out)
 {
 	unsigned long long m = 0;
@@ -382,6 +505,9 @@ struct cs_extender {
 	cse::ExtParams P{};
 	bool packed16 = true;                 // the two-columns-per-lane int16 kernel may be used (parameters fit; not switched off)
 	int min_qlen16 = 64;
+	bool lanes = true;                    // short queries go through extend_lanes_kernel (one pair per lane)
+	void *d_keys = nullptr, *d_keys2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_sort = nullptr; size_t c_keys = 0, c_keys2 = 0, c_idx = 0, c_idx2 = 0, c_sort = 0;
+	unsigned long long *d_cls = nullptr, *h_cls = nullptr; // pairs per query-length class of the lane kernel
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	void *d_pairs = nullptr, *d_q = nullptr, *d_t = nullptr, *d_out = nullptr, *d_scratch = nullptr; size_t c_pairs = 0, c_q = 0, c_t = 0, c_out = 0, c_scratch = 0;
 	uint64_t res_q = 0, res_t = 0;                         // bytes of the sequence buffers uploaded by cs_extender_upload
@@ -439,6 +565,9 @@ extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_ext
 	if (e == hipSuccess) e = hipMalloc((void **)&x->d_ctr, 8 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_ctr, 8 * sizeof(unsigned long long), hipHostMallocDefault);
 	if (e == hipSuccess) e = hipMemcpy(x->d_ctr + 4, par->mat, 25, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMalloc((void **)&x->d_cls, 8 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_cls, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+	x->lanes = !x->packed16 && !(par->flags & CS_EXT_NO_LANES);
 	if (e != hipSuccess) { (void)hipGetLastError(); cs_extender_destroy(x); return cs_fail_(CS_EDEVICE, std::string("cs_extender_create: ") + hipGetErrorString(e)); }
 	*out = x;
 	return CS_OK;
@@ -449,8 +578,9 @@ extern "C" void cs_extender_destroy(cs_extender_t *x)
 	if (!x) return;
 	(void)hipSetDevice(x->device);
 	if (x->stream) (void)hipStreamSynchronize(x->stream);
-	for (void *p : {x->d_pairs, x->d_q, x->d_t, x->d_out, x->d_scratch, (void *)x->d_ctr}) if (p) (void)hipFree(p);
+	for (void *p : {x->d_pairs, x->d_q, x->d_t, x->d_out, x->d_scratch, (void *)x->d_ctr, x->d_keys, x->d_keys2, x->d_idx, x->d_idx2, x->d_sort, (void *)x->d_cls}) if (p) (void)hipFree(p);
 	if (x->h_ctr) (void)hipHostFree(x->h_ctr);
+	if (x->h_cls) (void)hipHostFree(x->h_cls);
 	if (x->ev0) (void)hipEventDestroy(x->ev0);
 	if (x->ev1) (void)hipEventDestroy(x->ev1);
 	if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -476,6 +606,36 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 	const size_t per_wave = ((size_t)2 * (A.max_qlen + 2) + ((A.max_qlen + 3) >> 2)) * 4; // bytes of LDS per wave
 	HIP_TRYX(hipEventRecord(x->ev0, s));
 	A.packed16 = 0; A.min_qlen16 = x->min_qlen16;
+	int64_t n_lanes = 0;
+	if (x->lanes && n < (1ll << 32)) { // short queries: one pair per lane, pairs sorted by (query-length class, target length, query length)
+		if (int rc = grow(&x->d_keys, &x->c_keys, (size_t)n * 4)) return rc;
+		if (int rc = grow(&x->d_keys2, &x->c_keys2, (size_t)n * 4)) return rc;
+		if (int rc = grow(&x->d_idx, &x->c_idx, (size_t)n * 4)) return rc;
+		if (int rc = grow(&x->d_idx2, &x->c_idx2, (size_t)n * 4)) return rc;
+		HIP_TRYX(hipMemsetAsync(x->d_cls, 0, 8 * sizeof(unsigned long long), s));
+		hipLaunchKernelGGL(cse::lanes_keys_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)x->n_cu * 8)), dim3(256), 0, s, A, (uint32_t *)x->d_keys, (uint32_t *)x->d_idx, x->d_cls);
+		HIP_TRYX(hipGetLastError());
+		HIP_TRYX(hipMemcpyAsync(x->h_cls, x->d_cls, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		size_t tb = 0;
+		HIP_TRYX(rocprim::radix_sort_pairs(nullptr, tb, (uint32_t *)x->d_keys, (uint32_t *)x->d_keys2, (uint32_t *)x->d_idx, (uint32_t *)x->d_idx2, (size_t)n, 0u, 32u, s));
+		if (int rc = grow(&x->d_sort, &x->c_sort, tb + 16)) return rc;
+		HIP_TRYX(rocprim::radix_sort_pairs(x->d_sort, tb, (uint32_t *)x->d_keys, (uint32_t *)x->d_keys2, (uint32_t *)x->d_idx, (uint32_t *)x->d_idx2, (size_t)n, 0u, 32u, s));
+		HIP_TRYX(hipStreamSynchronize(s));
+		int64_t first = 0;
+		for (int c = 0; c < 4; ++c) {
+			const int64_t cnt = (int64_t)x->h_cls[c];
+			if (cnt > 0) {
+				const int qmax = cse::LANES_QCLASS[c];
+				const size_t lds = (size_t)(qmax + 2) * 256 + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
+				hipLaunchKernelGGL(cse::extend_lanes_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, s, A, (const uint32_t *)x->d_idx2, first, cnt, qmax);
+				HIP_TRYX(hipGetLastError());
+			}
+			first += cnt;
+		}
+		n_lanes = first;
+		A.packed16 = 1;                    // extend_kernel below takes only what the key kernel marked DECLINED
+	}
+	if (n_lanes == n) goto done;          // (nothing left for the wave-per-pair kernels)
 	{ // the pairs of the 16-bit class first, two columns per lane (declines what does not fit: those get DECLINED as their score) ...
 		const size_t per_wave16 = (size_t)3 * ((A.max_qlen + 4) >> 1) * 4;
 		if (x->packed16 && per_wave16 <= 60 * 1024) {
@@ -498,6 +658,7 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 		hipLaunchKernelGGL(cse::extend_kernel<false>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0, s, A);
 	}
 	HIP_TRYX(hipGetLastError());
+done:
 	HIP_TRYX(hipEventRecord(x->ev1, s));
 	HIP_TRYX(hipMemcpyAsync(x->h_ctr, x->d_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 	HIP_TRYX(hipStreamSynchronize(s));
