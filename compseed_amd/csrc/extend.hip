@@ -377,41 +377,52 @@ __global__ __launch_bounds__(256, 8) void extend16_kernel(const ExtArgs A)
 // lane in LDS -- H and E of a column packed into one dword (scores of this class are below 2^15), the lanes interleaved so that a
 // wave's access to "its column" never conflicts: (qmax + 2) x 256 bytes per wave, plus the query bytes.  Pairs outside the class
 // (longer queries, scores that may reach 2^15, the scalar scoring rule) are left to extend_kernel.
-constexpr int LANES_QCLASS[4] = {48, 80, 112, 160};                                     // query-length classes: one launch (and LDS size) each
-__device__ __host__ __forceinline__ int lanes_class_of(int qlen) { return qlen <= 48 ? 0 : qlen <= 80 ? 1 : qlen <= 112 ? 2 : qlen <= 160 ? 3 : 4; }
+constexpr int LANES_NCLASS = 8;
+constexpr int LANES_QCLASS[LANES_NCLASS] = {32, 48, 64, 80, 96, 112, 136, 160};          // query-length classes: one launch (and LDS size: 8.8 .. 51.7 KB per wave) each
+__device__ __host__ __forceinline__ int lanes_class_of(int qlen)
+{
+	return qlen <= 64 ? (qlen <= 32 ? 0 : qlen <= 48 ? 1 : 2) : qlen <= 112 ? (qlen <= 80 ? 3 : qlen <= 96 ? 4 : 5) : qlen <= 136 ? 6 : qlen <= 160 ? 7 : LANES_NCLASS;
+}
 
 // sort key of a pair for the lane kernel: class | target length | query length; 0xffffffff = not for the lane kernel (its result's score
 // is set to DECLINED so that extend_kernel takes it)
 __global__ void lanes_keys_kernel(const ExtArgs A, uint32_t *keys, uint32_t *idx, unsigned long long *class_cnt)
 {
-	__shared__ unsigned int cnt[4];                                        // (one atomic per block and class on the global counters: 2 M lanes on four words took 12 ms)
-	if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+	__shared__ unsigned int cnt[2 * LANES_NCLASS];                                        // (one atomic per block and class on the global counters: 2 M lanes on four words took 12 ms)
+	if (threadIdx.x < 2 * LANES_NCLASS) cnt[threadIdx.x] = 0;
 	__syncthreads();
 	for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.n; p += (int64_t)gridDim.x * blockDim.x) {
 		const cs_ext_pair_t pr = A.pairs[p];
 		const bool ok = pr.qlen >= 1 && pr.tlen >= 0 && pr.tlen < 32768 && pr.q_off <= A.q_bytes && (uint64_t)pr.qlen <= A.q_bytes - pr.q_off && pr.t_off <= A.t_bytes &&
 		                (uint64_t)pr.tlen <= A.t_bytes - pr.t_off && pr.h0 >= 0;
-		const int cls = ok ? lanes_class_of(pr.qlen) : 4;
+		const int cls = ok ? lanes_class_of(pr.qlen) : LANES_NCLASS;
 		// every score of the extension stays below h0 + qlen x match: it has to fit 15 bits (and the reference's vectorised scoring rule applies)
-		const bool fits = cls < 4 && (int64_t)pr.h0 + (int64_t)pr.qlen * A.P.best < 32000;
-		if (fits) keys[p] = (uint32_t)cls << 28 | (uint32_t)pr.tlen << 12 | (uint32_t)pr.qlen;
+		const bool fits = cls < LANES_NCLASS && (int64_t)pr.h0 + (int64_t)pr.qlen * A.P.best < 32000;
+		const bool narrow = (int64_t)pr.h0 + (int64_t)pr.qlen * A.P.best <= 255;   // 8-bit scores: classes 0 .. 7; 16-bit: 8 .. 15
+		const int kc = narrow ? cls : cls + LANES_NCLASS;
+		if (fits) keys[p] = (uint32_t)kc << 27 | (uint32_t)pr.tlen << 12 | (uint32_t)pr.qlen;
 		else { keys[p] = 0xffffffffu; A.out[p].score = DECLINED; }
 		idx[p] = (uint32_t)p;
-		for (int c = 0; c < 4; ++c) { // (the lanes of a wave that are in this iteration, counted per class by one of them)
-			const unsigned long long mk = __ballot(fits && cls == c);
+		for (int c = 0; c < 2 * LANES_NCLASS; ++c) { // (the lanes of a wave that are in this iteration, counted per class by one of them)
+			const unsigned long long mk = __ballot(fits && kc == c);
 			if (mk && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) atomicAdd(&cnt[c], (unsigned)__builtin_popcountll(mk));
 		}
 	}
 	__syncthreads();
-	if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(class_cnt + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
+	if (threadIdx.x < 2 * LANES_NCLASS && cnt[threadIdx.x]) atomicAdd(class_cnt + threadIdx.x, (unsigned long long)cnt[threadIdx.x]);
 }
 
+// CellT uint32_t: H | E << 16 (scores below 2^15); uint16_t: H | E << 8 for the pairs whose scores stay below 256 -- h0 + qlen x match <= 255,
+// the reference's own 8-bit class (getScores8), which is most extensions of a 150-bp read: half the LDS, twice the waves per CU
+template <typename CellT>
 __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const uint32_t *order, int64_t first, int64_t count, int qmax)
 {
 	extern __shared__ uint32_t lsm[];
+	constexpr int SH = sizeof(CellT) * 4;                                // bits of a score field
+	constexpr uint32_t FM = (1u << SH) - 1u;
 	const int lane = threadIdx.x;
-	uint32_t *eh = lsm + lane;                                           // column j of this lane: eh[j * 64] = H | E << 16
-	uint8_t *qs = reinterpret_cast<uint8_t *>(lsm + (size_t)(qmax + 2) * 64) + lane; // query base j of this lane: qs[j * 64]
+	CellT *eh = reinterpret_cast<CellT *>(lsm) + lane;                   // column j of this lane: eh[j * 64] = H | E << SH
+	uint8_t *qs = reinterpret_cast<uint8_t *>(reinterpret_cast<CellT *>(lsm) + (size_t)(qmax + 2) * 64) + lane; // query base j of this lane: qs[j * 64]
 	const int64_t k = (int64_t)blockIdx.x * 64 + lane;
 	const bool have = k < count;
 	const int64_t p = have ? (int64_t)order[first + k] : 0;
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const
 	// row "-1" (ksw.c:398-400) and the query
 	if (have) {
 		const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
-		for (int j = 0; j <= qlen + 1; ++j) eh[j * 64] = (uint32_t)(j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0);
+		for (int j = 0; j <= qlen + 1; ++j) eh[j * 64] = (CellT)(j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0);
 		for (int j = 0; j < qlen; ++j) qs[j * 64] = qg[j];
 	}
 	int w = A.w;
@@ -445,22 +456,23 @@ __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const
 		int h1 = beg == 0 ? imax(h0 - (P.o_del + e_del * (i + 1)), 0) : 0;   // H(i, beg - 1) (ksw.c:419-423)
 		int f = 0, best = 0;                                                  // best = row maximum << 16 | its LAST column (ksw.c:440-441): one max per cell
 		const int s_eq = ti == 4 ? -1 : P.match, s_ne = ti == 4 ? -1 : P.mismatch;
-		uint32_t cell_n = eh[beg * 64]; int q_n = (int)qs[beg * 64];         // (column j + 1 is fetched while column j is computed: a lane has no neighbours to hide LDS latency behind)
+		uint32_t cell_n = (uint32_t)eh[beg * 64]; int q_n = (int)qs[beg * 64];         // (column j + 1 is fetched while column j is computed: a lane has no neighbours to hide LDS latency behind)
+#pragma unroll 4
 		for (int j = beg; j < end; ++j) {
 			const uint32_t cell = cell_n; const int qj = q_n;
-			cell_n = eh[(j + 1) * 64]; q_n = (int)qs[(j + 1) * 64];
-			int M = (int)(cell & 0xffffu), e = (int)(cell >> 16);
+			cell_n = (uint32_t)eh[(j + 1) * 64]; q_n = (int)qs[(j + 1) * 64];
+			int M = (int)(cell & FM), e = (int)(cell >> SH);
 			const int sc = qj == 4 ? -1 : (qj == ti ? s_eq : s_ne);
 			M = M != 0 ? M + sc : 0;                                        // a path may not restart from a zero cell (ksw.c:436)
 			const int h = imax(imax(M, e), f);
 			e = imax(e - e_del, imax(M - oe_del, 0));
-			eh[j * 64] = (uint32_t)h1 | (uint32_t)e << 16;                  // H(i, j-1): the diagonal of column j in the next row; E(i+1, j)
+			eh[j * 64] = (CellT)((uint32_t)h1 | (uint32_t)e << SH);                // H(i, j-1): the diagonal of column j in the next row; E(i+1, j)
 			h1 = h;
 			best = imax(best, h << 16 | j);
 			f = imax(f - e_ins, imax(M - oe_ins, 0));
 		}
 		const int m = best >> 16, mj = best & 0xffff;
-		eh[end * 64] = (uint32_t)h1;
+		eh[end * 64] = (CellT)h1;
 		my_cells += (unsigned)(end > beg ? end - beg : 0); ++my_rows;
 		if ((beg < end ? end : beg) == qlen) { // the row reached the end of the query (ksw.c:452-455)
 			if (!(g_best > h1)) g_row = i;
@@ -565,8 +577,8 @@ extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_ext
 	if (e == hipSuccess) e = hipMalloc((void **)&x->d_ctr, 8 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_ctr, 8 * sizeof(unsigned long long), hipHostMallocDefault);
 	if (e == hipSuccess) e = hipMemcpy(x->d_ctr + 4, par->mat, 25, hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMalloc((void **)&x->d_cls, 8 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_cls, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+	if (e == hipSuccess) e = hipMalloc((void **)&x->d_cls, 16 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_cls, 16 * sizeof(unsigned long long), hipHostMallocDefault);
 	x->lanes = !x->packed16 && !(par->flags & CS_EXT_NO_LANES);
 	if (e != hipSuccess) { (void)hipGetLastError(); cs_extender_destroy(x); return cs_fail_(CS_EDEVICE, std::string("cs_extender_create: ") + hipGetErrorString(e)); }
 	*out = x;
@@ -612,22 +624,24 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 		if (int rc = grow(&x->d_keys2, &x->c_keys2, (size_t)n * 4)) return rc;
 		if (int rc = grow(&x->d_idx, &x->c_idx, (size_t)n * 4)) return rc;
 		if (int rc = grow(&x->d_idx2, &x->c_idx2, (size_t)n * 4)) return rc;
-		HIP_TRYX(hipMemsetAsync(x->d_cls, 0, 8 * sizeof(unsigned long long), s));
+		HIP_TRYX(hipMemsetAsync(x->d_cls, 0, 16 * sizeof(unsigned long long), s));
 		hipLaunchKernelGGL(cse::lanes_keys_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)x->n_cu * 8)), dim3(256), 0, s, A, (uint32_t *)x->d_keys, (uint32_t *)x->d_idx, x->d_cls);
 		HIP_TRYX(hipGetLastError());
-		HIP_TRYX(hipMemcpyAsync(x->h_cls, x->d_cls, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		HIP_TRYX(hipMemcpyAsync(x->h_cls, x->d_cls, 2 * cse::LANES_NCLASS * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
 		size_t tb = 0;
 		HIP_TRYX(rocprim::radix_sort_pairs(nullptr, tb, (uint32_t *)x->d_keys, (uint32_t *)x->d_keys2, (uint32_t *)x->d_idx, (uint32_t *)x->d_idx2, (size_t)n, 0u, 32u, s));
 		if (int rc = grow(&x->d_sort, &x->c_sort, tb + 16)) return rc;
 		HIP_TRYX(rocprim::radix_sort_pairs(x->d_sort, tb, (uint32_t *)x->d_keys, (uint32_t *)x->d_keys2, (uint32_t *)x->d_idx, (uint32_t *)x->d_idx2, (size_t)n, 0u, 32u, s));
 		HIP_TRYX(hipStreamSynchronize(s));
 		int64_t first = 0;
-		for (int c = 0; c < 4; ++c) {
+		for (int c = 0; c < 2 * cse::LANES_NCLASS; ++c) {
 			const int64_t cnt = (int64_t)x->h_cls[c];
 			if (cnt > 0) {
-				const int qmax = cse::LANES_QCLASS[c];
-				const size_t lds = (size_t)(qmax + 2) * 256 + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
-				hipLaunchKernelGGL(cse::extend_lanes_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, s, A, (const uint32_t *)x->d_idx2, first, cnt, qmax);
+				const bool narrow = c < cse::LANES_NCLASS;
+				const int qmax = cse::LANES_QCLASS[c % cse::LANES_NCLASS];
+				const size_t lds = (size_t)(qmax + 2) * 64 * (narrow ? 2 : 4) + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
+				if (narrow) hipLaunchKernelGGL(cse::extend_lanes_kernel<uint16_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, s, A, (const uint32_t *)x->d_idx2, first, cnt, qmax);
+				else hipLaunchKernelGGL(cse::extend_lanes_kernel<uint32_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, s, A, (const uint32_t *)x->d_idx2, first, cnt, qmax);
 				HIP_TRYX(hipGetLastError());
 			}
 			first += cnt;
