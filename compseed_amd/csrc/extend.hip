@@ -521,6 +521,7 @@ struct cs_extender {
 	void *d_keys = nullptr, *d_keys2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_sort = nullptr; size_t c_keys = 0, c_keys2 = 0, c_idx = 0, c_idx2 = 0, c_sort = 0;
 	unsigned long long *d_cls = nullptr, *h_cls = nullptr; // pairs per query-length class of the lane kernel
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}; // the lane kernel's class launches run side by side
 	void *d_pairs = nullptr, *d_q = nullptr, *d_t = nullptr, *d_out = nullptr, *d_scratch = nullptr; size_t c_pairs = 0, c_q = 0, c_t = 0, c_out = 0, c_scratch = 0;
 	uint64_t res_q = 0, res_t = 0;                         // bytes of the sequence buffers uploaded by cs_extender_upload
 	unsigned long long *d_ctr = nullptr, *h_ctr = nullptr; // device words: [0] skipped pairs [1] cells [2] rows [3] longest query; [4..7] hold the matrix
@@ -574,6 +575,8 @@ extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_ext
 	hipError_t e = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&x->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&x->ev1);
+	for (int k = 0; k < 2 && e == hipSuccess; ++k) { e = hipStreamCreateWithFlags(&x->side[k], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_join[k], hipEventDisableTiming); }
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipMalloc((void **)&x->d_ctr, 8 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_ctr, 8 * sizeof(unsigned long long), hipHostMallocDefault);
 	if (e == hipSuccess) e = hipMemcpy(x->d_ctr + 4, par->mat, 25, hipMemcpyHostToDevice);
@@ -595,6 +598,8 @@ extern "C" void cs_extender_destroy(cs_extender_t *x)
 	if (x->h_cls) (void)hipHostFree(x->h_cls);
 	if (x->ev0) (void)hipEventDestroy(x->ev0);
 	if (x->ev1) (void)hipEventDestroy(x->ev1);
+	for (int k = 0; k < 2; ++k) { if (x->ev_join[k]) (void)hipEventDestroy(x->ev_join[k]); if (x->side[k]) { (void)hipStreamSynchronize(x->side[k]); (void)hipStreamDestroy(x->side[k]); } }
+	if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
 	if (x->stream) (void)hipStreamDestroy(x->stream);
 	delete x;
 }
@@ -634,18 +639,26 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 		HIP_TRYX(rocprim::radix_sort_pairs(x->d_sort, tb, (uint32_t *)x->d_keys, (uint32_t *)x->d_keys2, (uint32_t *)x->d_idx, (uint32_t *)x->d_idx2, (size_t)n, 0u, 32u, s));
 		HIP_TRYX(hipStreamSynchronize(s));
 		int64_t first = 0;
-		for (int c = 0; c < 2 * cse::LANES_NCLASS; ++c) {
+		// one launch per class (its LDS size), the largest first, spread over three streams: the tail of one class is filled by the next
+		HIP_TRYX(hipEventRecord(x->ev_fork, s));
+		for (int k = 0; k < 2; ++k) HIP_TRYX(hipStreamWaitEvent(x->side[k], x->ev_fork, 0));
+		int64_t start[2 * cse::LANES_NCLASS]; int by_size[2 * cse::LANES_NCLASS];
+		for (int c = 0; c < 2 * cse::LANES_NCLASS; ++c) { start[c] = first; first += (int64_t)x->h_cls[c]; by_size[c] = c; }
+		std::sort(by_size, by_size + 2 * cse::LANES_NCLASS, [&](int a, int b) { return x->h_cls[a] > x->h_cls[b]; });
+		int nl = 0;
+		for (int o = 0; o < 2 * cse::LANES_NCLASS; ++o) {
+			const int c = by_size[o];
 			const int64_t cnt = (int64_t)x->h_cls[c];
-			if (cnt > 0) {
-				const bool narrow = c < cse::LANES_NCLASS;
-				const int qmax = cse::LANES_QCLASS[c % cse::LANES_NCLASS];
-				const size_t lds = (size_t)(qmax + 2) * 64 * (narrow ? 2 : 4) + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
-				if (narrow) hipLaunchKernelGGL(cse::extend_lanes_kernel<uint16_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, s, A, (const uint32_t *)x->d_idx2, first, cnt, qmax);
-				else hipLaunchKernelGGL(cse::extend_lanes_kernel<uint32_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, s, A, (const uint32_t *)x->d_idx2, first, cnt, qmax);
-				HIP_TRYX(hipGetLastError());
-			}
-			first += cnt;
+			if (cnt <= 0) continue;
+			const bool narrow = c < cse::LANES_NCLASS;
+			const int qmax = cse::LANES_QCLASS[c % cse::LANES_NCLASS];
+			const size_t lds = (size_t)(qmax + 2) * 64 * (narrow ? 2 : 4) + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
+			hipStream_t ls = nl % 3 == 0 ? s : x->side[nl % 3 - 1]; ++nl;
+			if (narrow) hipLaunchKernelGGL(cse::extend_lanes_kernel<uint16_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
+			else hipLaunchKernelGGL(cse::extend_lanes_kernel<uint32_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
+			HIP_TRYX(hipGetLastError());
 		}
+		for (int k = 0; k < 2; ++k) { HIP_TRYX(hipEventRecord(x->ev_join[k], x->side[k])); HIP_TRYX(hipStreamWaitEvent(s, x->ev_join[k], 0)); }
 		n_lanes = first;
 		A.packed16 = 1;                    // extend_kernel below takes only what the key kernel marked DECLINED
 	}
