@@ -414,11 +414,13 @@ __global__ void lanes_keys_kernel(const ExtArgs A, uint32_t *keys, uint32_t *idx
 
 // CellT uint32_t: H | E << 16 (scores below 2^15); uint16_t: H | E << 8 for the pairs whose scores stay below 256 -- h0 + qlen x match <= 255,
 // the reference's own 8-bit class (getScores8), which is most extensions of a 150-bp read: half the LDS, twice the waves per CU
-template <typename CellT>
+// QIN (with 8-bit scores only): the query base sits in the cell's third byte -- a dword per column that is the lane's own (no bank
+// conflicts, one LDS read per cell instead of two) for a third more LDS than the 16-bit cell + query byte
+template <typename CellT, bool QIN>
 __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const uint32_t *order, int64_t first, int64_t count, int qmax)
 {
 	extern __shared__ uint32_t lsm[];
-	constexpr int SH = sizeof(CellT) * 4;                                // bits of a score field
+	constexpr int SH = QIN ? 8 : sizeof(CellT) * 4;                      // bits of a score field
 	constexpr uint32_t FM = (1u << SH) - 1u;
 	const int lane = threadIdx.x;
 	CellT *eh = reinterpret_cast<CellT *>(lsm) + lane;                   // column j of this lane: eh[j * 64] = H | E << SH
@@ -434,8 +436,8 @@ __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const
 	// row "-1" (ksw.c:398-400) and the query
 	if (have) {
 		const int v1 = h0 > oe_ins ? h0 - oe_ins : 0;
-		for (int j = 0; j <= qlen + 1; ++j) eh[j * 64] = (CellT)(j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0);
-		for (int j = 0; j < qlen; ++j) qs[j * 64] = qg[j];
+		for (int j = 0; j <= qlen + 1; ++j) eh[j * 64] = (CellT)((uint32_t)(j == 0 ? h0 : j <= qlen ? imax(v1 - (j - 1) * e_ins, 0) : 0) | (QIN && j < qlen ? (uint32_t)qg[j] << 16 : 0u));
+		if (!QIN) for (int j = 0; j < qlen; ++j) qs[j * 64] = qg[j];
 	}
 	int w = A.w;
 	{ // the band cannot usefully be wider than the longest gap the best possible score pays for (ksw.c:402-410)
@@ -456,23 +458,24 @@ __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const
 		int h1 = beg == 0 ? imax(h0 - (P.o_del + e_del * (i + 1)), 0) : 0;   // H(i, beg - 1) (ksw.c:419-423)
 		int f = 0, best = 0;                                                  // best = row maximum << 16 | its LAST column (ksw.c:440-441): one max per cell
 		const int s_eq = ti == 4 ? -1 : P.match, s_ne = ti == 4 ? -1 : P.mismatch;
-		uint32_t cell_n = (uint32_t)eh[beg * 64]; int q_n = (int)qs[beg * 64];         // (column j + 1 is fetched while column j is computed: a lane has no neighbours to hide LDS latency behind)
+		uint32_t cell_n = (uint32_t)eh[beg * 64]; int q_n = QIN ? 0 : (int)qs[beg * 64];         // (column j + 1 is fetched while column j is computed: a lane has no neighbours to hide LDS latency behind)
 #pragma unroll 4
 		for (int j = beg; j < end; ++j) {
-			const uint32_t cell = cell_n; const int qj = q_n;
-			cell_n = (uint32_t)eh[(j + 1) * 64]; q_n = (int)qs[(j + 1) * 64];
-			int M = (int)(cell & FM), e = (int)(cell >> SH);
+			const uint32_t cell = cell_n; const int qj = QIN ? (int)((cell >> 16) & 0xffu) : q_n;
+			cell_n = (uint32_t)eh[(j + 1) * 64]; if (!QIN) q_n = (int)qs[(j + 1) * 64];
+			int M = (int)(cell & FM), e = (int)((cell >> SH) & FM);
 			const int sc = qj == 4 ? -1 : (qj == ti ? s_eq : s_ne);
 			M = M != 0 ? M + sc : 0;                                        // a path may not restart from a zero cell (ksw.c:436)
 			const int h = imax(imax(M, e), f);
 			e = imax(e - e_del, imax(M - oe_del, 0));
-			eh[j * 64] = (CellT)((uint32_t)h1 | (uint32_t)e << SH);                // H(i, j-1): the diagonal of column j in the next row; E(i+1, j)
+			if (QIN) *reinterpret_cast<uint16_t *>(&eh[j * 64]) = (uint16_t)((uint32_t)h1 | (uint32_t)e << 8);   // (the low half: the base stays)
+			else eh[j * 64] = (CellT)((uint32_t)h1 | (uint32_t)e << SH);                // H(i, j-1): the diagonal of column j in the next row; E(i+1, j)
 			h1 = h;
 			best = imax(best, h << 16 | j);
 			f = imax(f - e_ins, imax(M - oe_ins, 0));
 		}
 		const int m = best >> 16, mj = best & 0xffff;
-		eh[end * 64] = (CellT)h1;
+		if (QIN) *reinterpret_cast<uint16_t *>(&eh[end * 64]) = (uint16_t)h1; else eh[end * 64] = (CellT)h1;
 		my_cells += (unsigned)(end > beg ? end - beg : 0); ++my_rows;
 		if ((beg < end ? end : beg) == qlen) { // the row reached the end of the query (ksw.c:452-455)
 			if (!(g_best > h1)) g_row = i;
@@ -490,9 +493,9 @@ __global__ __launch_bounds__(64) void extend_lanes_kernel(const ExtArgs A, const
 		// the live columns (ksw.c:470-473 look at the arrays as this row leaves them): the zero cells at either edge are usually none or one,
 		// so two short scans are cheaper than keeping track of them in every cell
 		int nbeg = beg;
-		while (nbeg < end && eh[nbeg * 64] == 0) ++nbeg;
+		while (nbeg < end && (QIN ? ((uint32_t)eh[nbeg * 64] & 0xffffu) : (uint32_t)eh[nbeg * 64]) == 0) ++nbeg;
 		int jz = end;
-		if (h1 == 0) { jz = end - 1; while (jz >= nbeg && eh[jz * 64] == 0) --jz; }
+		if (h1 == 0) { jz = end - 1; while (jz >= nbeg && (QIN ? ((uint32_t)eh[jz * 64] & 0xffffu) : (uint32_t)eh[jz * 64]) == 0) --jz; }
 		beg = nbeg; end = jz + 2 < qlen ? jz + 2 : qlen;
 	}
 	if (have) { cs_ext_result_t r = {top, top_j + 1, top_i + 1, g_row + 1, g_best, off}; A.out[p] = r; }
@@ -518,6 +521,7 @@ struct cs_extender {
 	bool packed16 = true;                 // the two-columns-per-lane int16 kernel may be used (parameters fit; not switched off)
 	int min_qlen16 = 64;
 	bool lanes = true;                    // short queries go through extend_lanes_kernel (one pair per lane)
+	bool qin = false;                     // ... with the query base inside the cell (CS_EXT_LANES_QIN: experiment)
 	void *d_keys = nullptr, *d_keys2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_sort = nullptr; size_t c_keys = 0, c_keys2 = 0, c_idx = 0, c_idx2 = 0, c_sort = 0;
 	unsigned long long *d_cls = nullptr, *h_cls = nullptr; // pairs per query-length class of the lane kernel
 	hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -583,6 +587,7 @@ extern "C" int cs_extender_create(int device, const cs_ext_params_t *par, cs_ext
 	if (e == hipSuccess) e = hipMalloc((void **)&x->d_cls, 16 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_cls, 16 * sizeof(unsigned long long), hipHostMallocDefault);
 	x->lanes = !x->packed16 && !(par->flags & CS_EXT_NO_LANES);
+	x->qin = (par->flags & CS_EXT_LANES_QIN) != 0;
 	if (e != hipSuccess) { (void)hipGetLastError(); cs_extender_destroy(x); return cs_fail_(CS_EDEVICE, std::string("cs_extender_create: ") + hipGetErrorString(e)); }
 	*out = x;
 	return CS_OK;
@@ -652,10 +657,12 @@ static int extend_device(cs_extender *x, int64_t n, const cs_ext_pair_t *d_pairs
 			if (cnt <= 0) continue;
 			const bool narrow = c < cse::LANES_NCLASS;
 			const int qmax = cse::LANES_QCLASS[c % cse::LANES_NCLASS];
-			const size_t lds = (size_t)(qmax + 2) * 64 * (narrow ? 2 : 4) + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
+			const bool qin = narrow && x->qin;
+			const size_t lds = qin ? (size_t)(qmax + 3) * 256 : (size_t)(qmax + 2) * 64 * (narrow ? 2 : 4) + (size_t)(qmax + 1) * 64;   // (+ 1 query row: the loop fetches one column ahead)
 			hipStream_t ls = nl % 3 == 0 ? s : x->side[nl % 3 - 1]; ++nl;
-			if (narrow) hipLaunchKernelGGL(cse::extend_lanes_kernel<uint16_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
-			else hipLaunchKernelGGL(cse::extend_lanes_kernel<uint32_t>, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
+			if (qin) hipLaunchKernelGGL((cse::extend_lanes_kernel<uint32_t, true>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
+			else if (narrow) hipLaunchKernelGGL((cse::extend_lanes_kernel<uint16_t, false>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
+			else hipLaunchKernelGGL((cse::extend_lanes_kernel<uint32_t, false>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), lds, ls, A, (const uint32_t *)x->d_idx2, start[c], cnt, qmax);
 			HIP_TRYX(hipGetLastError());
 		}
 		for (int k = 0; k < 2; ++k) { HIP_TRYX(hipEventRecord(x->ev_join[k], x->side[k])); HIP_TRYX(hipStreamWaitEvent(s, x->ev_join[k], 0)); }

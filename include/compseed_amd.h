@@ -339,6 +339,7 @@ typedef struct { int8_t mat[25]; int32_t o_del, e_del, o_ins, e_ins, zdrop, end_
 #define CS_EXT_PACKED16     1u   /* flags: queries longer than 64 bases go through the second kernel (two columns per lane, packed int16); exact, */
 #define CS_EXT_PACKED16_ALL 2u   /* ... all queries of the 16-bit class do.  Default 0: one column per lane for everything (faster on 150-bp reads)    */
 #define CS_EXT_NO_LANES     4u   /* do not use the one-pair-per-lane kernel for short queries (A/B tests): every pair goes one wave per pair */
+#define CS_EXT_LANES_QIN    8u   /* lane kernel, 8-bit class: the query base inside the score cell (one LDS read per cell, a third more LDS); exact; an experiment */
 typedef struct { uint64_t q_off, t_off; int32_t qlen, tlen, h0, reserved; } cs_ext_pair_t;
 typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } cs_ext_result_t;
 typedef struct { uint64_t pairs, cells, rows, launches; double kernel_ms; } cs_ext_stats_t;   /* cells = DP cells computed (inside the adaptive band) */

@@ -28,7 +28,7 @@ def _run_fixture(ca, fx, flags=0):
     return got
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2], ids=["default", "packed16 above 64 bases", "packed16 for all"])   # CS_EXT_PACKED16 / CS_EXT_PACKED16_ALL: every mix of the two kernels must give the reference's numbers
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8], ids=["default (lane per pair)", "packed16 above 64 bases", "packed16 for all", "wave per pair only", "lane per pair, base in the cell"])   # CS_EXT_*: every kernel and every mix of them must give the reference's numbers
 @pytest.mark.parametrize("tag", TRACES)
 def test_every_extension_of_the_reference_run(tag, flags):
     import compseed_amd as ca

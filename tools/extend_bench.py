@@ -50,7 +50,7 @@ def make_pairs(n, dev, seed=5):
     return pairs, qbuf, tbuf
 
 
-def run(n_pairs=2_000_000, steps=5, check=20000, cpu_pairs=200000, cpu_threads=16, device=0, lib=None):
+def run(n_pairs=2_000_000, steps=5, check=20000, cpu_pairs=200000, cpu_threads=16, device=0, lib=None, flags=0):
     import torch
     import compseed_amd as ca
     import _oracle
@@ -63,7 +63,7 @@ def run(n_pairs=2_000_000, steps=5, check=20000, cpu_pairs=200000, cpu_threads=1
     d_o = torch.zeros(n_pairs * 24, dtype=torch.uint8, device=dev)
     q_bytes, t_bytes = d_q.numel(), d_t.numel()
     torch.cuda.synchronize()
-    x = ca.Extender(device)
+    x = ca.Extender(device, ca.ExtParams(flags=flags)) if flags else ca.Extender(device)
     x.extend_device(d_p.data_ptr(), n_pairs, d_q.data_ptr(), q_bytes, d_t.data_ptr(), t_bytes, d_o.data_ptr(), 100)   # warm-up
     s0 = x.stats()
     t0 = time.perf_counter()
@@ -128,6 +128,6 @@ def run(n_pairs=2_000_000, steps=5, check=20000, cpu_pairs=200000, cpu_threads=1
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=2_000_000); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--cpu-pairs", type=int, default=200000)
+    ap.add_argument("--pairs", type=int, default=2_000_000); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--cpu-pairs", type=int, default=200000); ap.add_argument("--flags", type=int, default=0, help="cs_ext_params_t.flags (CS_EXT_*)")
     a = ap.parse_args()
-    print(json.dumps(run(a.pairs, a.steps, cpu_pairs=a.cpu_pairs)))
+    print(json.dumps(run(a.pairs, a.steps, cpu_pairs=a.cpu_pairs, flags=a.flags)))
