@@ -12,7 +12,10 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <memory>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -55,7 +58,7 @@ extern "C" void cs_aln_params_default(cs_aln_params_t *p)
 	if (!p) return;
 	// mem_opt_init (comp_seed.cpp:26-58)
 	p->a = 1; p->b = 4; p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1; p->pen_clip5 = p->pen_clip3 = 5; p->w = 100; p->zdrop = 100;
-	p->threads = 8;
+	p->threads = 16;
 }
 
 extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_params_t *par, cs_aligner_t **out)
@@ -100,8 +103,13 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 	const cs_aln_params_t &o = A->par;
 	const cs_refseq_view &R = A->ref;
 	const int64_t n = chains->n_reads, l_pac = R.l_pac;
+#ifdef CS_ALIGN_TIMING
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[cs_extend_chains] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
+#else
+	auto lap = [](const char *) {};
+#endif
 	A->reg_off.assign((size_t)n + 1, 0); A->regs.clear();
-	A->regs.reserve((size_t)chains->n_seeds);
 
 	// Host work is per read and independent: T threads take contiguous read ranges; each builds its regions, jobs and target windows into
 	// buffers of its own, which are then joined (region and window offsets shifted by what the ranges before it produced).
@@ -122,11 +130,12 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 			for (uint64_t j = 0; j < len; ++j) { const uint8_t c = base_code(bases[b0 + j]); qbuf[b0 + j] = c; qbuf[n_bases + b0 + (len - 1 - j)] = c; }
 		}
 	});
+	lap("queries (codes, reversed)");
 	// Targets: per chain the reference window [w0, w1) the chain's seeds can reach (comp_seed.cpp:1395-1428), forward and reversed.
 	struct Meta { int64_t read; const cs_seed_t *seeds; int32_t n_seeds; };   // per region: what the later passes need
 	struct Part { std::vector<cs_alnreg_t> regs; std::vector<Meta> meta; std::vector<Job> left, right; std::vector<int32_t> h0_left; std::vector<uint8_t> tbuf; bool bad = false; };
 	std::vector<Part> part((size_t)T);
-	std::vector<std::vector<uint32_t>> order_of_chain((size_t)chains->n_chains); // seeds in the order they were extended (for the purge pass)
+	std::vector<uint32_t> order_flat((size_t)chains->n_seeds);                      // per chain (at its cseed_off): its seeds in the order they were extended (for the purge pass)
 	for_ranges([&](int t, int64_t r0, int64_t r1) {
 		Part &P = part[(size_t)t];
 		for (int64_t r = r0; r < r1; ++r) {
@@ -164,10 +173,9 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 					P.tbuf[(size_t)(tb0 + k)] = b; P.tbuf[(size_t)(tb0 + L + (L - 1 - k))] = b;
 				}
 				// seeds by score, highest first, later ones first among equals (ks_introsort over score << 32 | index, walked from the top: comp_seed.cpp:1440-1458)
-				std::vector<uint32_t> &ord = order_of_chain[(size_t)ci];
-				ord.resize((size_t)ns);
+				uint32_t *ord = order_flat.data() + chains->cseed_off[ci];
 				for (int i = 0; i < ns; ++i) ord[(size_t)i] = (uint32_t)i;
-				std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+				std::sort(ord, ord + ns, [&](uint32_t x, uint32_t y) {
 					const int sx = sc ? sc[x] : sd[x].len, sy = sc ? sc[y] : sd[y].len;
 					return sx != sy ? sx > sy : x > y;
 				});
@@ -197,32 +205,37 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 			A->reg_off[(size_t)r + 1] = P.regs.size();                                  // (local count so far; made global below)
 		}
 	});
+	lap("windows, regions, jobs");
 	for (const Part &P : part) if (P.bad) return cs_fail_(CS_EINVAL, "cs_extend_chains: a chain's first seed lies outside the reference");
 	// join the ranges
-	std::vector<uint8_t> tbuf; std::vector<Job> left, right; std::vector<Meta> meta; std::vector<int32_t> h0_left;
+	std::unique_ptr<uint8_t[]> tbuf; size_t tbuf_bytes = 0;                           // (not a vector: nobody needs 10 GB of zeros written first)
+	std::vector<Job> left, right; std::vector<Meta> meta; std::vector<int32_t> h0_left;
 	{
 		size_t nr = 0, nt = 0, nl = 0, nrt = 0;
 		for (const Part &P : part) { nr += P.regs.size(); nt += P.tbuf.size(); nl += P.left.size(); nrt += P.right.size(); }
 		if (nr >= 0xffffffffull) return cs_fail_(CS_ERANGE, "cs_extend_chains: more than 2^32 regions in one call");
-		A->regs.reserve(nr); meta.reserve(nr); tbuf.resize(nt); left.reserve(nl); right.reserve(nrt); h0_left.reserve(nl);
-		size_t reg_base = 0, t_base = 0;
+		A->regs.resize(nr); meta.resize(nr); tbuf.reset(new uint8_t[nt + 8]); tbuf_bytes = nt; left.resize(nl); right.resize(nrt); h0_left.resize(nl);
+		std::vector<size_t> reg_base((size_t)T + 1, 0), t_base((size_t)T + 1, 0), l_base((size_t)T + 1, 0), r_base((size_t)T + 1, 0);
 		for (int t = 0; t < T; ++t) {
-			Part &P = part[(size_t)t];
-			for (int64_t r = n * t / T; r < n * (t + 1) / T; ++r) A->reg_off[(size_t)r + 1] += reg_base;
-			if (!P.tbuf.empty()) memcpy(tbuf.data() + t_base, P.tbuf.data(), P.tbuf.size());
-			for (Job j : P.left) { j.reg += (uint32_t)reg_base; j.t_off += (int64_t)t_base; left.push_back(j); }
-			for (Job j : P.right) { j.reg += (uint32_t)reg_base; j.t_off += (int64_t)t_base; right.push_back(j); }
-			h0_left.insert(h0_left.end(), P.h0_left.begin(), P.h0_left.end());
-			A->regs.insert(A->regs.end(), P.regs.begin(), P.regs.end());
-			meta.insert(meta.end(), P.meta.begin(), P.meta.end());
-			reg_base += P.regs.size(); t_base += P.tbuf.size();
-			P = Part();
+			reg_base[(size_t)t + 1] = reg_base[(size_t)t] + part[(size_t)t].regs.size(); t_base[(size_t)t + 1] = t_base[(size_t)t] + part[(size_t)t].tbuf.size();
+			l_base[(size_t)t + 1] = l_base[(size_t)t] + part[(size_t)t].left.size(); r_base[(size_t)t + 1] = r_base[(size_t)t] + part[(size_t)t].right.size();
 		}
+		for_ranges([&](int t, int64_t r0, int64_t r1) { // every range copies its own share to where the prefix sums say
+			Part &P = part[(size_t)t];
+			const size_t rb = reg_base[(size_t)t], tb = t_base[(size_t)t];
+			for (int64_t r = r0; r < r1; ++r) A->reg_off[(size_t)r + 1] += rb;
+			if (!P.tbuf.empty()) memcpy(tbuf.get() + tb, P.tbuf.data(), P.tbuf.size());
+			for (size_t i = 0; i < P.left.size(); ++i) { Job j = P.left[i]; j.reg += (uint32_t)rb; j.t_off += (int64_t)tb; left[l_base[(size_t)t] + i] = j; h0_left[l_base[(size_t)t] + i] = P.h0_left[i]; }
+			for (size_t i = 0; i < P.right.size(); ++i) { Job j = P.right[i]; j.reg += (uint32_t)rb; j.t_off += (int64_t)tb; right[r_base[(size_t)t] + i] = j; }
+			if (!P.regs.empty()) { memcpy(A->regs.data() + rb, P.regs.data(), P.regs.size() * sizeof(cs_alnreg_t)); memcpy(meta.data() + rb, P.meta.data(), P.meta.size() * sizeof(Meta)); }
+			P = Part();
+		});
 	}
-
+	lap("join");
 	// ---- the dynamic programming, on the GPU: sequences go up once, each band try moves its pairs and results only
-	int rc = cs_extender_upload(A->ext, qbuf.data(), qbuf.size(), tbuf.empty() ? nullptr : tbuf.data(), tbuf.size());
+	int rc = cs_extender_upload(A->ext, qbuf.data(), qbuf.size(), tbuf_bytes ? tbuf.get() : nullptr, tbuf_bytes);
 	if (rc != CS_OK) return rc;
+	lap("upload sequences");
 	std::vector<cs_ext_pair_t> pairs; std::vector<cs_ext_result_t> res;
 	auto run_side = [&](std::vector<Job> &jobs, std::vector<int32_t> &h0, bool is_left, int pen_clip) -> int {
 		for (int attempt = 0; attempt < 2 && !jobs.empty(); ++attempt) { // MAX_BAND_TRY (comp_seed.cpp:423)
@@ -257,10 +270,12 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 	};
 	rc = run_side(left, h0_left, true, o.pen_clip5);
 	if (rc != CS_OK) return rc;
+	lap("left side (2 tries)");
 	std::vector<int32_t> h0_right(right.size());
 	for (size_t i = 0; i < right.size(); ++i) h0_right[i] = A->regs[right[i].reg].score;   // the right side starts from what the left side reached (comp_seed.cpp:1917-1922)
 	rc = run_side(right, h0_right, false, o.pen_clip3);
 	if (rc != CS_OK) return rc;
+	lap("right side (2 tries)");
 
 	// ---- seed coverage of the final region: the chain's seeds that lie inside it on both axes (comp_seed.cpp:1758-1766)
 	for_ranges([&](int, int64_t r0, int64_t r1) {
@@ -275,6 +290,7 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 		}
 	});
 
+	lap("seed coverage");
 	// ---- purge (comp_seed.cpp:2141-2232): walking the seeds in the order they were extended, a seed that lies inside an earlier, surviving
 	// region of its read, is not much longer than that region's seed, and sits within the band of its diagonal at either end is redundant
 	// -- unless a later-ranked seed of its chain overlaps it on another diagonal.  Its region is marked qb = qe = -1.
@@ -287,8 +303,8 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 		size_t g = g0; int kept = 0;
 		for (uint64_t ci = chains->chain_off[r]; ci < chains->chain_off[r + 1]; ++ci) {
 			const cs_seed_t *sd = chains->cseeds + chains->cseed_off[ci];
-			std::vector<uint32_t> &ord = order_of_chain[(size_t)ci];
-			const int ns = (int)ord.size();
+			uint32_t *ord = order_flat.data() + chains->cseed_off[ci];
+			const int ns = (int)(chains->cseed_off[ci + 1] - chains->cseed_off[ci]);
 			// `ord` is descending; the reference indexes the ascending array from the top, k = ns - 1 .. 0, i.e. position ns - 1 - k here
 			for (int k = 0; k < ns; ++k, ++g) {
 				const cs_seed_t &s = sd[ord[(size_t)k]];
@@ -323,6 +339,7 @@ extern "C" int cs_extend_chains(cs_aligner_t *A, const cs_chain_result_t *chains
 	}
 	n_purged += my_purged;
 	});
+	lap("purge");
 	A->st.purged += n_purged.load();
 	A->st.reads += (uint64_t)n; A->st.regions += A->regs.size();
 	out->n_reads = n; out->n_regs = A->regs.size(); out->reg_off = A->reg_off.data(); out->regs = A->regs.data();

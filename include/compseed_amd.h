@@ -367,7 +367,7 @@ int  cs_extend_batch_resident(cs_extender_t *x, int64_t n_pairs, const cs_ext_pa
  *      batch's reads (ASCII or codes; a '-' is code 5 as in nst_nt4_table).  The aligner loads <prefix>.ann / .alt / .pac.  The result arrays
  *      belong to the aligner and stay valid until its next call.  pen_clip5 must equal pen_clip3 for now. */
 typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop; /* mem_opt_t: -A -B -O -E -L -w -d */
-                 int32_t threads;   /* [8] host threads that build windows / pairs and run the passes around the kernel */ } cs_aln_params_t;
+                 int32_t threads;   /* [16] host threads that build windows / pairs and run the passes around the kernel */ } cs_aln_params_t;
 typedef struct { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0; float frac_rep; int32_t chain; } cs_alnreg_t;
 typedef struct { int64_t n_reads; uint64_t n_regs; const uint64_t *reg_off; const cs_alnreg_t *regs; } cs_aln_result_t;
 typedef struct { uint64_t reads, regions, pairs, retries, purged, launches; } cs_aln_stats_t;   /* pairs = extensions run incl. retries */
