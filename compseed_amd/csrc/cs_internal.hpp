@@ -40,3 +40,10 @@ void cs_pack_reads_host_(const uint8_t *bases, const uint64_t *offsets, int64_t 
 struct cs_aligner_core { const cs_refseq_view *ref; const std::vector<uint8_t> *pac; const cs_aln_params_t *par; };
 int cs_dedup_regions_(const cs_aligner_core &A, const cs_dedup_params_t *par, const cs_aln_result_t *regs, const uint8_t *bases, const uint64_t *read_offsets,
                       std::vector<uint64_t> &out_off, std::vector<cs_alnreg_t> &out_regs, std::vector<int32_t> &out_ncomp);
+
+// the device side of cs_extend_chains (align_gpu.hip): windows, regions, pair lists, result passes and the purge as kernels
+struct cs_aligner_gpu;
+void cs_aligner_gpu_release_(cs_aligner_gpu *g);
+int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, const cs_refseq_view &R, const std::vector<uint8_t> &pac, const cs_aln_params_t &o,
+                          const cs_chain_result_t *chains, const int32_t *cseed_score, const uint8_t *bases, const uint64_t *read_offsets,
+                          std::vector<uint64_t> &reg_off, std::vector<cs_alnreg_t> &regs, cs_aln_stats_t &st);
