@@ -16,6 +16,8 @@
 #include "cs_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -217,51 +219,69 @@ __global__ void seedcov_kernel(const Args A) // the chain's seeds that lie insid
 }
 // comp_seed.cpp:2141-2232: walking a read's seeds in the order they were extended, a seed that lies inside an earlier, surviving region of
 // the read, is not much longer than that region's seed and sits within the band of its diagonal at either end is redundant -- unless a
-// higher-ranked seed of its chain overlaps it on another diagonal.  Its region is marked qb = qe = -1.  One thread per read.
-__global__ void purge_kernel(const Args A)
+// higher-ranked seed of its chain that is still in play overlaps it on another diagonal.  Its region is marked qb = qe = -1.
+// One WAVE per read: the walk over the read's regions is sequential (a region's fate decides about the later ones), but both tests are
+// "is there one among the earlier ...", so the lanes take the earlier regions / the higher-ranked seeds 64 at a time and a ballot answers.
+// (One thread per read took 1.5 s for 400,000 reads with 68 regions each; this takes a few ms.)  Which regions are purged so far is kept
+// in a byte array that is read around the L1 (volatile): lane 0 writes, the whole wave reads in the next step.
+__global__ void purge_kernel(const Args A, uint8_t *pflag)
 {
 	const cs_aln_params_t &o = A.o;
+	volatile uint8_t *pf = pflag;
+	const int lane = threadIdx.x & 63;
+	const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 	unsigned long long my = 0;
-	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < A.n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+	for (int64_t r = wave; r < A.n_reads; r += n_waves) {
 		const int l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
-		const uint64_t g0 = A.cseed_off[A.chain_off[r]], g1 = A.cseed_off[A.chain_off[r + 1]];
-		uint64_t g = g0; int kept = 0;
+		const uint64_t g0 = A.cseed_off[A.chain_off[r]];
+		uint64_t g = g0;
 		for (uint64_t ci = A.chain_off[r]; ci < A.chain_off[r + 1]; ++ci) {
-			const cs_seed_t *sd = A.cseeds + A.cseed_off[ci];
-			uint32_t *ord = A.ord + A.cseed_off[ci];
-			const int ns = (int)(A.cseed_off[ci + 1] - A.cseed_off[ci]);
+			const uint64_t s0 = A.cseed_off[ci];
+			const cs_seed_t *sd = A.cseeds + s0;
+			const uint32_t *ord = A.ord + s0;
+			const int ns = (int)(A.cseed_off[ci + 1] - s0);
 			for (int k = 0; k < ns; ++k, ++g) {
 				const cs_seed_t s = sd[ord[k]];
-				int seen = 0; bool around = false;
-				for (uint64_t i = g0; i < g1 && seen < kept; ++i) {
-					const cs_alnreg_t p = A.regs[i];
-					if (p.qb == -1 && p.qe == -1) continue;
-					if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) { ++seen; continue; }
-					if (s.len - p.seedlen0 > .1 * l_query) { ++seen; continue; }
-					int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
-					int gap = affordable_gap(o, (int)(qd < rd ? qd : rd)), w = gap < p.w ? gap : p.w;
-					if (qd - rd < w && rd - qd < w) { around = true; break; }
-					qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-					gap = affordable_gap(o, (int)(qd < rd ? qd : rd)); w = gap < p.w ? gap : p.w;
-					if (qd - rd < w && rd - qd < w) { around = true; break; }
-					++seen;
-				}
-				if (around) {
-					bool rival = false;
-					for (int v = k - 1; v >= 0 && !rival; --v) { // seeds ranked above this one that are still in play
-						if (ord[v] == 0xffffffffu) continue;
-						const cs_seed_t t = sd[ord[v]];
-						if (t.len < s.len * .95) continue;
-						if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) rival = true;
-						else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) rival = true;
+				bool around = false;
+				for (uint64_t base = g0; base < g && !around; base += 64) { // the earlier regions of the read that survive
+					const uint64_t i = base + (uint64_t)lane;
+					bool hit = false;
+					if (i < g && !pf[i]) {
+						const cs_alnreg_t p = A.regs[i];
+						if (!(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) && !(s.len - p.seedlen0 > .1 * l_query)) {
+							int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
+							int gap = affordable_gap(o, (int)(qd < rd ? qd : rd)), w = gap < p.w ? gap : p.w;
+							if (qd - rd < w && rd - qd < w) hit = true;
+							else {
+								qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+								gap = affordable_gap(o, (int)(qd < rd ? qd : rd)); w = gap < p.w ? gap : p.w;
+								if (qd - rd < w && rd - qd < w) hit = true;
+							}
+						}
 					}
-					if (!rival) { A.regs[g].qb = -1; A.regs[g].qe = -1; ord[k] = 0xffffffffu; ++my; continue; }
+					around = __ballot(hit) != 0;
 				}
-				++kept;
+				if (!around) continue;
+				bool rival = false;
+				for (int base = 0; base < k && !rival; base += 64) { // seeds ranked above this one that are still in play
+					const int v = base + lane;
+					bool hit = false;
+					if (v < k && !pf[s0 + (uint64_t)v]) {
+						const cs_seed_t t = sd[ord[v]];
+						if (!(t.len < s.len * .95)) {
+							if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) hit = true;
+							else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
+						}
+					}
+					rival = __ballot(hit) != 0;
+				}
+				if (rival) continue;
+				if (lane == 0) { pf[g] = 1; A.regs[g].qb = -1; A.regs[g].qe = -1; ++my; }
+				__threadfence();
 			}
 		}
 	}
-	if (my) atomicAdd(A.ctr + 4, my);
+	if (lane == 0 && my) atomicAdd(A.ctr + 4, my);
 }
 } // namespace csa
 
@@ -278,7 +298,7 @@ int ensure(Buf &b, size_t bytes)
 	return CS_OK;
 }
 enum { B_CHAIN_OFF, B_CSEED_OFF, B_READ_OFF, B_CHAINS, B_CSEEDS, B_SCORE, B_BASES, B_PAC, B_CTG_OFF, B_CTG_LEN, B_CHAIN_READ, B_W0, B_WLEN2, B_TB0, B_QBUF, B_TBUF, B_ORD, B_REGS,
-       B_REG_CI, B_LP, B_RP, B_RETRY, B_RES, B_CTR, B_SCAN, B_COUNT };
+       B_REG_CI, B_LP, B_RP, B_RETRY, B_RES, B_CTR, B_SCAN, B_PFLAG, B_COUNT };
 } // namespace
 
 struct cs_aligner_gpu { int device = 0, n_cu = 256; hipStream_t s = nullptr; Buf b[B_COUNT]; bool pac_up = false; unsigned long long *h_ctr = nullptr; };
@@ -308,6 +328,12 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	}
 	cs_aligner_gpu &G = **gp;
 	hipStream_t s = G.s;
+#ifdef CS_ALIGN_TIMING
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { (void)hipStreamSynchronize(s); const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[cs_extend_chains] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
+#else
+	auto lap = [](const char *) {};
+#endif
 	const int64_t n = chains->n_reads, nc = (int64_t)chains->n_chains, ns = (int64_t)chains->n_seeds;
 	reg_off.assign((size_t)n + 1, 0); regs.clear();
 	for (int64_t r = 0; r < n; ++r) reg_off[(size_t)r + 1] = chains->cseed_off[chains->chain_off[r + 1]];
@@ -335,6 +361,7 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 		HIP_TRYA(hipStreamSynchronize(s));          // (co / cl are locals)
 		G.pac_up = true;
 	}
+	lap("uploads");
 	for (int which : {B_CHAIN_READ}) if (int rc = ensure(G.b[which], (size_t)nc * 4 + 64)) return rc;
 	for (int which : {B_W0, B_WLEN2, B_TB0}) if (int rc = ensure(G.b[which], ((size_t)nc + 1) * 8 + 64)) return rc;
 	if (int rc = ensure(G.b[B_QBUF], (size_t)n_bases * 2 + 64)) return rc;
@@ -356,6 +383,7 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	A.lp = (cs_ext_pair_t *)G.b[B_LP].p; A.rp = (cs_ext_pair_t *)G.b[B_RP].p; A.ctr = (unsigned long long *)G.b[B_CTR].p;
 	auto grid = [&](int64_t items, int per_block = 256) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + per_block - 1) / per_block, (int64_t)G.n_cu * 16))); };
 
+	lap("buffers");
 	hipLaunchKernelGGL(csa::chain_read_kernel, grid(n), dim3(256), 0, s, A);
 	hipLaunchKernelGGL(csa::query_kernel, grid((int64_t)n_bases), dim3(256), 0, s, A);
 	hipLaunchKernelGGL(csa::window_kernel, grid(nc), dim3(256), 0, s, A);
@@ -371,6 +399,7 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	HIP_TRYA(hipMemcpyAsync(G.h_ctr + 1, A.ctr + 3, 8, hipMemcpyDeviceToHost, s));
 	HIP_TRYA(hipStreamSynchronize(s));
 	if (G.h_ctr[1]) return cs_fail_(CS_EINVAL, "cs_extend_chains: a chain's first seed lies outside the reference");
+	lap("queries, windows, scan");
 	const uint64_t t_bytes = G.h_ctr[0];
 	if (int rc = ensure(G.b[B_TBUF], (size_t)t_bytes + 64)) return rc;
 	A.tbuf = (uint8_t *)G.b[B_TBUF].p;
@@ -380,6 +409,7 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	HIP_TRYA(hipMemcpyAsync(G.h_ctr, A.ctr, 2 * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRYA(hipStreamSynchronize(s));
 	const uint64_t n_left = G.h_ctr[0], n_right = G.h_ctr[1];
+	lap("fill, regions");
 
 	// ---- the dynamic programming (extend.hip), each side: band w, then 2w for the pairs whose path came close to the band's edge
 	auto run_side = [&](cs_ext_pair_t *pairs, uint64_t cnt, bool is_left, int pen_clip) -> int {
@@ -400,16 +430,24 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 		return CS_OK;
 	};
 	if (int rc = run_side(A.lp, n_left, true, o.pen_clip5)) return rc;
+	lap("left side");
 	if (n_right) { hipLaunchKernelGGL(csa::right_h0_kernel, grid((int64_t)n_right), dim3(256), 0, s, A.rp, n_right, (const cs_alnreg_t *)A.regs); HIP_TRYA(hipGetLastError()); HIP_TRYA(hipStreamSynchronize(s)); }
 	if (int rc = run_side(A.rp, n_right, false, o.pen_clip3)) return rc;
 
+	lap("right side");
 	hipLaunchKernelGGL(csa::seedcov_kernel, grid(ns), dim3(256), 0, s, A);
-	hipLaunchKernelGGL(csa::purge_kernel, grid(n, 64), dim3(64), 0, s, A);
+	lap("seedcov");
+	if (int rc = ensure(G.b[B_PFLAG], (size_t)ns + 64)) return rc;
+	HIP_TRYA(hipMemsetAsync(G.b[B_PFLAG].p, 0, (size_t)ns, s));
+	hipLaunchKernelGGL(csa::purge_kernel, grid(n * 64), dim3(256), 0, s, A, (uint8_t *)G.b[B_PFLAG].p);
 	HIP_TRYA(hipGetLastError());
+	lap("purge");
 	regs.resize((size_t)ns);
+	lap("host resize");
 	HIP_TRYA(hipMemcpyAsync(regs.data(), A.regs, (size_t)ns * sizeof(cs_alnreg_t), hipMemcpyDeviceToHost, s));
 	HIP_TRYA(hipMemcpyAsync(G.h_ctr, A.ctr + 4, 8, hipMemcpyDeviceToHost, s));
 	HIP_TRYA(hipStreamSynchronize(s));
+	lap("download");
 	st.purged += G.h_ctr[0]; st.regions += (uint64_t)ns;
 	return CS_OK;
 }
