@@ -104,3 +104,31 @@ def test_engine_chainer_aligner_end_to_end():
     assert (g["rb"][live] >= 0).all() and (g["re"][live] > g["rb"][live]).all() and (g["score"][live] >= g["seedlen0"][live]).all()
     assert live.sum() > 1000
     al.close(); ch.close(); eng.close(); ix.close()
+
+
+def test_degenerate_inputs():
+    """no reads; reads without chains; a chain the seed test left without seeds: empty or pass-through results, error codes for bad CSR"""
+    import compseed_amd as ca
+    al = ca.Aligner(_data.PREFIX, 0)
+    z = np.zeros
+    got = al.extend_chains(z(1, np.uint64), z(0, ca.CHAIN_DT), z(1, np.uint64), z(0, ca.SEED_DT), z(0, np.uint8), z(1, np.uint64))
+    assert got["regs"].size == 0 and np.array_equal(got["reg_off"], [0])
+    bases, off = _data.load_reads("sorted150")
+    bases, off = bases[:int(off[3])], off[:4]
+    got = al.extend_chains(z(4, np.uint64), z(0, ca.CHAIN_DT), z(1, np.uint64), z(0, ca.SEED_DT), bases, off)      # three reads, no chains
+    assert got["regs"].size == 0 and np.array_equal(got["reg_off"], [0, 0, 0, 0])
+    zz, _, _ = _load("sorted150")
+    # the first read's first chain, once as it is and once emptied: the emptied one contributes nothing
+    n0 = int(zz["chain_n"][0])
+    chains = np.zeros(2, dtype=ca.CHAIN_DT)
+    for f, k in (("pos", "chain_pos"), ("rid", "chain_rid"), ("frac_rep", "chain_frac_rep"), ("is_alt", "chain_is_alt")):
+        chains[f] = zz[k][0]
+    chains["n_seeds"] = [n0, 0]
+    cseeds = np.zeros(n0, dtype=ca.SEED_DT)
+    cseeds["rbeg"], cseeds["qbeg"], cseeds["len"] = zz["cseed_rbeg"][:n0], zz["cseed_qbeg"][:n0], zz["cseed_len"][:n0]
+    b1, o1 = bases[:int(off[1])], off[:2]
+    got = al.extend_chains(np.array([0, 2], np.uint64), chains, np.array([0, n0, n0], np.uint64), cseeds, b1, o1, cseed_score=zz["cseed_score"][:n0])
+    assert got["regs"].size == n0 and np.array_equal(got["regs"]["score"], zz["reg_score"][:n0])
+    with pytest.raises(ca.CSError):
+        al.extend_chains(np.array([0, 2], np.uint64), chains, np.array([0, n0 - 1, n0], np.uint64), cseeds, b1, o1)   # offsets that do not match the seed counts
+    al.close()
