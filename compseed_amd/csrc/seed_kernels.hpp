@@ -277,20 +277,42 @@ __global__ void sal_count_kernel(const OutMem *mems, uint64_t n_mems, uint32_t m
 
 struct OutSeed { int64_t rbeg; int32_t qbeg, len; }; // == cs_seed_t
 
-// GATHER: the slot is looked up in the HBM-resident full suffix array right here (one pass over the seeds instead of two)
+// GATHER: the slot is looked up in the HBM-resident full suffix array right here (one pass over the seeds instead of two).
+// A lane per mem, but a mem with more than SAL_LIGHT slots (a repeat: up to max_occ = 500 of them) is expanded by the whole wave, 64 slots
+// at a time with coalesced stores -- one lane looping over 500 slots while 63 wait was what SAL cost on repeat-rich genomes.
+constexpr uint32_t SAL_LIGHT = 4;
 template <bool GATHER>
 __global__ void sal_expand_kernel(const DevIndex ix, const OutMem *mems, uint64_t n_mems, uint32_t max_occ, const uint64_t *seed_of_mem, OutSeed *seeds)
 {
-	uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (m >= n_mems) return;
-	OutMem v = mems[m];
-	uint64_t step = v.x2 > max_occ ? v.x2 / max_occ : 1;
-	OutSeed *dst = seeds + seed_of_mem[m];
-	int32_t qb = (int32_t)(v.info >> 32), ln = (int32_t)(uint32_t)v.info - qb;
-	uint64_t cntr = 0;
-	for (uint64_t k = 0; k < v.x2 && cntr < max_occ; k += step, ++cntr) {
-		OutSeed s = {GATHER ? (int64_t)sa_direct(ix, v.x0 + k) : (int64_t)(v.x0 + k), qb, ln};
-		dst[cntr] = s;
+	const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const bool valid = m < n_mems;
+	OutMem v = valid ? mems[m] : OutMem{0, 0, 0, 0};
+	const uint64_t step = v.x2 > max_occ ? v.x2 / max_occ : 1;
+	const uint64_t first = valid ? seed_of_mem[m] : 0;
+	// slots of this mem (comp_seed.cpp:2313-2325: k = 0, step, 2 step, ... below x2, at most max_occ of them)
+	const uint64_t by_step = (v.x2 + step - 1) / step;
+	const uint32_t cnt = valid ? (uint32_t)(by_step < max_occ ? by_step : max_occ) : 0;
+	const int32_t qb = (int32_t)(v.info >> 32), ln = (int32_t)(uint32_t)v.info - qb;
+	if (cnt <= SAL_LIGHT) {
+		OutSeed *dst = seeds + first;
+		for (uint32_t c = 0; c < cnt; ++c) {
+			const uint64_t slot = v.x0 + (uint64_t)c * step;
+			OutSeed s = {GATHER ? (int64_t)sa_direct(ix, slot) : (int64_t)slot, qb, ln};
+			dst[c] = s;
+		}
+	}
+	unsigned long long heavy = __ballot(cnt > SAL_LIGHT);
+	while (heavy) { // wave-uniform
+		const int j = __builtin_ctzll(heavy); heavy &= heavy - 1;
+		const uint64_t x0 = __shfl(v.x0, j), st = __shfl(step, j), fj = __shfl(first, j);
+		const uint32_t cj = __shfl(cnt, j);
+		const int32_t qbj = __shfl(qb, j), lnj = __shfl(ln, j);
+		for (uint32_t c = (uint32_t)lane; c < cj; c += 64) {
+			const uint64_t slot = x0 + (uint64_t)c * st;
+			OutSeed s = {GATHER ? (int64_t)sa_direct(ix, slot) : (int64_t)slot, qbj, lnj};
+			seeds[fj + c] = s;
+		}
 	}
 }
 
