@@ -203,7 +203,8 @@ int  cs_engine_seed_batch_device(cs_engine_t *e, const cs_params_t *par, int64_t
  * (the reference's kt_for over chunks of a batch, comp_seed.cpp:2541-2548, is the same overlap on CPU threads).  Inputs as for
  * cs_engine_seed_batch_device, and they must stay untouched until their batch has been collected.  Results come back in submission
  * order; the device pointers of a collected batch stay valid until the SECOND submit after its collect (the next batch on its context).
- * While device batches are in flight the other entry points that use the device return CS_EINVAL. */
+ * While device batches are in flight the other entry points that use the device return CS_EINVAL.  Threads: as for cs_engine_submit /
+ * cs_engine_collect_packed -- one submitting thread, one collecting thread. */
 int  cs_engine_submit_device(cs_engine_t *e, const cs_params_t *par, int64_t n_reads,
                              const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_bases);
 int  cs_engine_collect_device(cs_engine_t *e, cs_result_t *out);
