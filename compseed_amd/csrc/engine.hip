@@ -1751,8 +1751,11 @@ extern "C" int cs_engine_collect_device(cs_engine_t *e, cs_result_t *out)
 	}
 	memset(out, 0, sizeof *out);
 	if (rc != CS_OK) return fail(rc, err);
-	invalidate_last(e);
-	c->last.valid = true; c->last.n_reads = n; c->last.n_mems = nm; c->last.n_seeds = ns; c->last.want_sal = sal; e->last_ctx = c;
+	{ // (a submit on another thread invalidates it under the same lock)
+		std::lock_guard<std::mutex> lk(dp.mu);
+		invalidate_last(e);
+		c->last.valid = !dev_pipe_busy(e); c->last.n_reads = n; c->last.n_mems = nm; c->last.n_seeds = ns; c->last.want_sal = sal; e->last_ctx = c;
+	}
 	out->n_reads = n; out->n_mems = nm; out->n_seeds = ns;
 	out->mem_off = c->d_mem_off.p; out->mems = (const cs_intv_t *)c->d_mems.p;
 	out->seed_off = sal ? c->d_seed_off.p : nullptr; out->seeds = sal ? (const cs_seed_t *)c->d_seeds.p : nullptr;
