@@ -169,7 +169,7 @@ class CAlnResult(C.Structure):
 
 
 class AlnStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("reads", "regions", "pairs", "retries", "purged", "launches")]
+    _fields_ = [(n, C.c_uint64) for n in ("reads", "regions", "pairs", "retries", "purged", "launches", "ext_cells")] + [("ext_kernel_ms", C.c_double)]
 
 
 class IndexCheck(C.Structure):
@@ -853,7 +853,7 @@ class Aligner:
     def stats(self):
         st = AlnStats()
         _check(self.L.cs_aligner_stats(self.h, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in AlnStats._fields_}
+        return {n: (float(getattr(st, n)) if n == "ext_kernel_ms" else int(getattr(st, n))) for n, _ in AlnStats._fields_}
 
     def close(self):
         if self.h:

@@ -102,5 +102,6 @@ extern "C" int cs_aligner_stats(const cs_aligner_t *A, cs_aln_stats_t *st)
 {
 	if (!A || !st) return cs_fail_(CS_EINVAL, "null argument");
 	*st = A->st;
+	if (A->ext) { cs_ext_stats_t x; if (cs_extender_stats(A->ext, &x) == CS_OK) { st->ext_cells = x.cells; st->ext_kernel_ms = x.kernel_ms; } } // (the extender is this aligner's own)
 	return CS_OK;
 }

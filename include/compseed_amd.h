@@ -371,7 +371,8 @@ typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3,
                  int32_t threads;   /* [16] host threads that build windows / pairs and run the passes around the kernel */ } cs_aln_params_t;
 typedef struct { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0; float frac_rep; int32_t chain; } cs_alnreg_t;
 typedef struct { int64_t n_reads; uint64_t n_regs; const uint64_t *reg_off; const cs_alnreg_t *regs; } cs_aln_result_t;
-typedef struct { uint64_t reads, regions, pairs, retries, purged, launches; } cs_aln_stats_t;   /* pairs = extensions run incl. retries */
+typedef struct { uint64_t reads, regions, pairs, retries, purged, launches;   /* pairs = extensions run incl. retries */
+                 uint64_t ext_cells; double ext_kernel_ms; } cs_aln_stats_t;     /* of the extension kernels: DP cells inside the adaptive band, HIP-event time */
 typedef struct cs_aligner cs_aligner_t;
 void cs_aln_params_default(cs_aln_params_t *p);
 int  cs_aligner_create(const char *prefix, int device /* -1: host-side passes only (cs_dedup_regions), no GPU needed */, const cs_aln_params_t *par /* NULL: defaults */, cs_aligner_t **out);

@@ -73,6 +73,9 @@ for name, a, b in (("seed (host call)", t0, t1), ("chain", t1, t2), ("chain_filt
     out[name] = {"ms": 1e3 * (b - a), "reads_per_s": n / (b - a)}
 out["counts"] = {"seeds": int(res.n_seeds), "chains": int(c["chains"].size), "chains_after_filter": int(f["chains"].size), "regions": int(g["regs"].size),
                  "regions_after_dedup": int(d["regs"].size), "extensions": int(st1["pairs"] - st0["pairs"]), "ext_launches": int(st1["launches"] - st0["launches"])}
+kms = st1["ext_kernel_ms"] - st0["ext_kernel_ms"]
+out["extension_kernels"] = {"ms": kms, "pairs_per_s": (st1["pairs"] - st0["pairs"]) / (kms * 1e-3) if kms > 0 else None, "dp_cells_per_pair": (st1["ext_cells"] - st0["ext_cells"]) / max(1, st1["pairs"] - st0["pairs"]),
+                            "note": "the extension kernels alone (HIP events) on this run's own pairs: extensions of real chains die at different rows, unlike the uniform pairs of tools/extend_bench.py"}
 t_all = sum(out[k]["ms"] for k in ("chain", "chain_filter", "extend_chains", "dedup_regions"))
 out["behind_seeding_reads_per_s"] = n / (t_all * 1e-3)
 print(json.dumps(out))
