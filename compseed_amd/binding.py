@@ -494,7 +494,7 @@ class Chainer:
         self._h = C.c_void_p()
         _check(load_library().cs_chainer_create(os.fsencode(prefix), C.byref(self._h)))
 
-    def chain(self, mem_off, mems, seed_off, seeds, read_offsets, params=None, threads=4):
+    def chain(self, mem_off, mems, seed_off, seeds, read_offsets, params=None, threads=4, copy=True):
         """host CSR seeds (numpy arrays as Result holds them) -> dict(chain_off, chains (CHAIN_DT), cseed_off, cseeds (SEED_DT)), copies"""
         params = params or ChainParams()
         mem_off = np.ascontiguousarray(mem_off, dtype=np.uint64); seed_off = np.ascontiguousarray(seed_off, dtype=np.uint64)
@@ -503,10 +503,10 @@ class Chainer:
         res = CResult(mem_off.size - 1, mems.size, seeds.size, mem_off.ctypes.data, mems.ctypes.data, seed_off.ctypes.data, seeds.ctypes.data)
         out = CChainResult()
         _check(load_library().cs_chain_batch(self._h, C.byref(params), C.byref(res), ro.ctypes.data, int(threads), C.byref(out)))
-        return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1), chains=_view(out.chains, CHAIN_DT, int(out.n_chains)),
-                    cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds)))
+        return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1, copy), chains=_view(out.chains, CHAIN_DT, int(out.n_chains), copy),
+                    cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1, copy), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds), copy))   # copy=False: views of the chainer's arrays, valid until its next chain()
 
-    def filter(self, chain_off, chains, cseed_off, cseeds, bases, read_offsets, params=None, threads=4):
+    def filter(self, chain_off, chains, cseed_off, cseeds, bases, read_offsets, params=None, threads=4, copy=True):
         """cs_chain_filter (mem_chain_flt + mem_flt_chained_seeds): chains as chain() returns them -> the same dict for the surviving
         chains in the reference's order, plus cseed_score (int32 per surviving seed); copies"""
         params = params or FltParams()
@@ -519,9 +519,9 @@ class Chainer:
         out = CChainResult(); sc = C.c_void_p()
         _check(load_library().cs_chain_filter(self._h, C.byref(params), C.byref(cin), bases.ctypes.data if bases is not None and bases.size else None, ro.ctypes.data,
                                               int(threads), C.byref(out), C.byref(sc)))
-        return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1), chains=_view(out.chains, CHAIN_DT, int(out.n_chains)),
-                    cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds)),
-                    cseed_score=_view(sc.value, "<i4", int(out.n_seeds)))
+        return dict(chain_off=_view(out.chain_off, "<u8", int(out.n_reads) + 1, copy), chains=_view(out.chains, CHAIN_DT, int(out.n_chains), copy),
+                    cseed_off=_view(out.cseed_off, "<u8", int(out.n_chains) + 1, copy), cseeds=_view(out.cseeds, SEED_DT, int(out.n_seeds), copy),
+                    cseed_score=_view(sc.value, "<i4", int(out.n_seeds), copy))
 
     def close(self):
         if self._h:
@@ -828,7 +828,7 @@ class Aligner:
         self.h = C.c_void_p()
         _check(self.L.cs_aligner_create(os.fsencode(prefix), device, C.byref(params) if params is not None else None, C.byref(self.h)))
 
-    def extend_chains(self, chain_off, chains, cseed_off, cseeds, bases, read_offsets, cseed_score=None):
+    def extend_chains(self, chain_off, chains, cseed_off, cseeds, bases, read_offsets, cseed_score=None, copy=True):
         """chains as Chainer.chain returns them (or the caller's own, e.g. filtered); returns dict(reg_off, regs (ALNREG_DT)), copies"""
         chain_off = np.ascontiguousarray(chain_off, dtype=np.uint64); cseed_off = np.ascontiguousarray(cseed_off, dtype=np.uint64)
         chains = np.ascontiguousarray(chains, dtype=CHAIN_DT); cseeds = np.ascontiguousarray(cseeds, dtype=SEED_DT)
@@ -838,9 +838,9 @@ class Aligner:
                           cseeds.ctypes.data if cseeds.size else None)
         out = CAlnResult()
         _check(self.L.cs_extend_chains(self.h, C.byref(cr), sc.ctypes.data if sc is not None and sc.size else None, bases.ctypes.data if bases.size else None, ro.ctypes.data, C.byref(out)))
-        return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1), regs=_view(out.regs, ALNREG_DT, int(out.n_regs)))
+        return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1, copy), regs=_view(out.regs, ALNREG_DT, int(out.n_regs), copy))
 
-    def dedup_regions(self, reg_off, regs, bases, read_offsets, params=None):
+    def dedup_regions(self, reg_off, regs, bases, read_offsets, params=None, copy=True):
         """cs_dedup_regions (purged regions dropped, mem_sort_dedup_patch): regions as extend_chains returns them -> dict(reg_off, regs, n_comp), copies"""
         params = params or DedupParams()
         reg_off = np.ascontiguousarray(reg_off, dtype=np.uint64); regs = np.ascontiguousarray(regs, dtype=ALNREG_DT)
@@ -848,7 +848,7 @@ class Aligner:
         cin = CAlnResult(reg_off.size - 1, regs.size, reg_off.ctypes.data, regs.ctypes.data if regs.size else None)
         out = CAlnResult(); nc = C.c_void_p()
         _check(self.L.cs_dedup_regions(self.h, C.byref(params), C.byref(cin), bases.ctypes.data if bases.size else None, ro.ctypes.data, C.byref(out), C.byref(nc)))
-        return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1), regs=_view(out.regs, ALNREG_DT, int(out.n_regs)), n_comp=_view(nc.value, "<i4", int(out.n_regs)))
+        return dict(reg_off=_view(out.reg_off, "<u8", int(out.n_reads) + 1, copy), regs=_view(out.regs, ALNREG_DT, int(out.n_regs), copy), n_comp=_view(nc.value, "<i4", int(out.n_regs), copy))
 
     def stats(self):
         st = AlnStats()

@@ -102,7 +102,9 @@ struct Tree { // node 0 is the root until it splits; nodes live in a vector that
 	}
 };
 
-struct Chain { int64_t pos; int32_t rid; std::vector<cs_seed_t> seeds; };
+// a chain while it grows: the merge rule only ever looks at its first and its last seed; the seeds themselves are a linked list through the
+// read's seed indices (next_of[]), so a read's chains cost no allocation of their own
+struct Chain { int64_t pos; int32_t rid, n; cs_seed_t head, tail; uint32_t first, last; };
 
 // contig of a forward-strand position (bns_pos2rid, bntseq.c:346-362): the last contig that starts at or before it
 inline int contig_of(const cs_refseq_view &R, int64_t fwd_pos)
@@ -123,10 +125,10 @@ inline int contig_of_seed(const cs_refseq_view &R, int64_t rb, int64_t re)
 // Does seed s belong to chain c (test_and_merge, comp_seed.cpp:182-203)?  Yes without a change when it lies inside the chain's
 // query and reference span; yes, appended, when it follows the chain's last seed on the same strand within the band `w` and
 // closer than max_chain_gap on both axes; otherwise a new chain starts.
-inline bool absorb(const cs_chain_params_t &opt, int64_t l_pac, Chain &c, const cs_seed_t &s, int seed_rid)
+inline bool absorb(const cs_chain_params_t &opt, int64_t l_pac, Chain &c, const cs_seed_t &s, int seed_rid, uint32_t s_idx, std::vector<uint32_t> &next_of)
 {
 	if (seed_rid != c.rid) return false;
-	const cs_seed_t &head = c.seeds.front(), &tail = c.seeds.back();
+	const cs_seed_t &head = c.head, &tail = c.tail;
 	const bool in_query = s.qbeg >= head.qbeg && s.qbeg + s.len <= tail.qbeg + tail.len;
 	const bool in_ref = s.rbeg >= head.rbeg && s.rbeg + s.len <= tail.rbeg + tail.len;
 	if (in_query && in_ref) return true;
@@ -136,7 +138,7 @@ inline bool absorb(const cs_chain_params_t &opt, int64_t l_pac, Chain &c, const 
 	const bool near_diag = dq - dr <= opt.w && dr - dq <= opt.w;
 	const bool close = dq - tail.len < opt.max_chain_gap && dr - tail.len < opt.max_chain_gap;
 	if (dr < 0 || !near_diag || !close) return false;
-	c.seeds.push_back(s);
+	next_of[c.last] = s_idx; c.last = s_idx; c.tail = s; ++c.n;
 	return true;
 }
 
@@ -144,19 +146,22 @@ struct ReadOut { std::vector<cs_chain_t> chains; std::vector<cs_seed_t> seeds; s
 
 void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs_result_t &S, const uint64_t *read_off, int64_t r0, int64_t r1, ReadOut &out)
 {
-	Tree tree; std::vector<Chain> pool;
+	Tree tree; std::vector<Chain> pool; std::vector<uint32_t> next_of;
 	for (int64_t r = r0; r < r1; ++r) {
 		const int len = (int)(read_off[r + 1] - read_off[r]);
 		uint32_t n_out = 0;
 		if (len >= opt.min_seed_len) {
 			tree.clear(); pool.clear();
+			const uint64_t s_base = S.seed_off[r];
+			next_of.assign((size_t)(S.seed_off[r + 1] - s_base), 0xffffffffu);
 			for (uint64_t si = S.seed_off[r]; si < S.seed_off[r + 1]; ++si) {
 				const cs_seed_t &s = S.seeds[si];
 				const int rid = contig_of_seed(R, s.rbeg, s.rbeg + s.len);
 				if (rid < 0) continue; // bridging two sequences or the forward-reverse boundary (comp_seed.cpp:251)
 				bool add = true;
-				if (tree.size) { const int lo = tree.lower(s.rbeg); if (lo >= 0 && absorb(opt, R.l_pac, pool[lo], s, rid)) add = false; }
-				if (add) { Chain c; c.pos = s.rbeg; c.rid = rid; c.seeds.push_back(s); pool.push_back(std::move(c)); tree.put(s.rbeg, (int32_t)pool.size() - 1); }
+				const uint32_t li = (uint32_t)(si - s_base);
+				if (tree.size) { const int lo = tree.lower(s.rbeg); if (lo >= 0 && absorb(opt, R.l_pac, pool[lo], s, rid, li, next_of)) add = false; }
+				if (add) { Chain c; c.pos = s.rbeg; c.rid = rid; c.n = 1; c.head = c.tail = s; c.first = c.last = li; pool.push_back(c); tree.put(s.rbeg, (int32_t)pool.size() - 1); }
 			}
 			// fraction of the read covered by repetitive mems (comp_seed.cpp:271-280); the mems are sorted by interval
 			int beg = 0, end = 0, l_rep = 0;
@@ -169,8 +174,9 @@ void chain_range(const cs_refseq_view &R, const cs_chain_params_t &opt, const cs
 			const float frac = (float)l_rep / len;
 			auto emit = [&](int32_t id) {
 				const Chain &c = pool[id];
-				cs_chain_t o; o.pos = c.pos; o.rid = c.rid; o.n_seeds = (int32_t)c.seeds.size(); o.frac_rep = frac; o.is_alt = R.is_alt[(size_t)c.rid]; // comp_seed.cpp:259
-				out.chains.push_back(o); out.seeds.insert(out.seeds.end(), c.seeds.begin(), c.seeds.end());
+				cs_chain_t o; o.pos = c.pos; o.rid = c.rid; o.n_seeds = c.n; o.frac_rep = frac; o.is_alt = R.is_alt[(size_t)c.rid]; // comp_seed.cpp:259
+				out.chains.push_back(o);
+				for (uint32_t k = c.first; k != 0xffffffffu; k = next_of[k]) out.seeds.push_back(S.seeds[s_base + k]);
 				++n_out;
 			};
 			if (tree.size) tree.traverse(tree.root, emit);
@@ -252,13 +258,22 @@ extern "C" int cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, con
 		else th.emplace_back(chain_range, std::cref(c->ref), std::cref(*par), std::cref(*seeds), read_offsets, r0, r1, std::ref(part[(size_t)t]));
 	}
 	for (auto &t : th) t.join();
-	c->chains.clear(); c->cseeds.clear(); c->chain_off.assign(1, 0); c->cseed_off.assign(1, 0);
-	for (auto &p : part) {
-		for (uint32_t k : p.per_read) c->chain_off.push_back(c->chain_off.back() + k);
-		for (const auto &ch : p.chains) c->cseed_off.push_back(c->cseed_off.back() + (uint64_t)ch.n_seeds);
-		c->chains.insert(c->chains.end(), p.chains.begin(), p.chains.end());
-		c->cseeds.insert(c->cseeds.end(), p.seeds.begin(), p.seeds.end());
-	}
+	// join: every thread's share goes to where the prefix sums over the threads say, copied by the threads side by side
+	std::vector<size_t> cb((size_t)T + 1, 0), sb((size_t)T + 1, 0);
+	for (int t = 0; t < T; ++t) { cb[(size_t)t + 1] = cb[(size_t)t] + part[(size_t)t].chains.size(); sb[(size_t)t + 1] = sb[(size_t)t] + part[(size_t)t].seeds.size(); }
+	c->chains.resize(cb[(size_t)T]); c->cseeds.resize(sb[(size_t)T]); c->chain_off.resize((size_t)n + 1); c->cseed_off.resize(cb[(size_t)T] + 1);
+	c->chain_off[0] = 0; c->cseed_off[0] = 0;
+	auto join = [&](int t) {
+		const ReadOut &p = part[(size_t)t];
+		uint64_t co = cb[(size_t)t], so = sb[(size_t)t];
+		int64_t r = n * t / T;
+		for (uint32_t k : p.per_read) { co += k; c->chain_off[(size_t)++r] = co; }
+		for (size_t i = 0; i < p.chains.size(); ++i) { so += (uint64_t)p.chains[i].n_seeds; c->cseed_off[cb[(size_t)t] + i + 1] = so; }
+		if (!p.chains.empty()) memcpy(c->chains.data() + cb[(size_t)t], p.chains.data(), p.chains.size() * sizeof(cs_chain_t));
+		if (!p.seeds.empty()) memcpy(c->cseeds.data() + sb[(size_t)t], p.seeds.data(), p.seeds.size() * sizeof(cs_seed_t));
+	};
+	if (T == 1) join(0);
+	else { std::vector<std::thread> tj; for (int t = 0; t < T; ++t) tj.emplace_back(join, t); for (auto &t : tj) t.join(); }
 	out->n_reads = n; out->n_chains = c->chains.size(); out->n_seeds = c->cseeds.size();
 	out->chain_off = c->chain_off.data(); out->chains = c->chains.data(); out->cseed_off = c->cseed_off.data(); out->cseeds = c->cseeds.data();
 	return CS_OK;

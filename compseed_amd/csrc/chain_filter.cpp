@@ -229,14 +229,22 @@ extern "C" int cs_chain_filter(cs_chainer_t *c, const cs_flt_params_t *par, cons
 		else th.emplace_back(filter_range, std::cref(*c), std::cref(*par), std::cref(*in), bases, read_offsets, r0, r1, std::ref(part[(size_t)t]));
 	}
 	for (auto &t : th) t.join();
-	c->f_chains.clear(); c->f_cseeds.clear(); c->f_score.clear(); c->f_chain_off.assign(1, 0); c->f_cseed_off.assign(1, 0);
-	for (auto &p : part) {
-		for (uint32_t k : p.per_read) c->f_chain_off.push_back(c->f_chain_off.back() + k);
-		for (const auto &ch : p.chains) c->f_cseed_off.push_back(c->f_cseed_off.back() + (uint64_t)ch.n_seeds);
-		c->f_chains.insert(c->f_chains.end(), p.chains.begin(), p.chains.end());
-		c->f_cseeds.insert(c->f_cseeds.end(), p.seeds.begin(), p.seeds.end());
-		c->f_score.insert(c->f_score.end(), p.score.begin(), p.score.end());
-	}
+	// join: every thread's share goes to where the prefix sums over the threads say, copied by the threads side by side
+	std::vector<size_t> cb((size_t)T + 1, 0), sb((size_t)T + 1, 0);
+	for (int t = 0; t < T; ++t) { cb[(size_t)t + 1] = cb[(size_t)t] + part[(size_t)t].chains.size(); sb[(size_t)t + 1] = sb[(size_t)t] + part[(size_t)t].seeds.size(); }
+	c->f_chains.resize(cb[(size_t)T]); c->f_cseeds.resize(sb[(size_t)T]); c->f_score.resize(sb[(size_t)T]); c->f_chain_off.resize((size_t)n + 1); c->f_cseed_off.resize(cb[(size_t)T] + 1);
+	c->f_chain_off[0] = 0; c->f_cseed_off[0] = 0;
+	auto join = [&](int t) {
+		const ReadOut &p = part[(size_t)t];
+		uint64_t co = cb[(size_t)t], so = sb[(size_t)t];
+		int64_t r = n * t / T;
+		for (uint32_t k : p.per_read) { co += k; c->f_chain_off[(size_t)++r] = co; }
+		for (size_t i = 0; i < p.chains.size(); ++i) { so += (uint64_t)p.chains[i].n_seeds; c->f_cseed_off[cb[(size_t)t] + i + 1] = so; }
+		if (!p.chains.empty()) memcpy(c->f_chains.data() + cb[(size_t)t], p.chains.data(), p.chains.size() * sizeof(cs_chain_t));
+		if (!p.seeds.empty()) { memcpy(c->f_cseeds.data() + sb[(size_t)t], p.seeds.data(), p.seeds.size() * sizeof(cs_seed_t)); memcpy(c->f_score.data() + sb[(size_t)t], p.score.data(), p.score.size() * sizeof(int32_t)); }
+	};
+	if (T == 1) join(0);
+	else { std::vector<std::thread> tj; for (int t = 0; t < T; ++t) tj.emplace_back(join, t); for (auto &t : tj) t.join(); }
 	out->n_reads = n; out->n_chains = c->f_chains.size(); out->n_seeds = c->f_cseeds.size();
 	out->chain_off = c->f_chain_off.data(); out->chains = c->f_chains.data(); out->cseed_off = c->f_cseed_off.data(); out->cseeds = c->f_cseeds.data();
 	if (cseed_score) *cseed_score = c->f_score.data();

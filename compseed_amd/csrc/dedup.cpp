@@ -193,10 +193,16 @@ int cs_dedup_regions_(const cs_aligner_core &A, const cs_dedup_params_t *par, co
 		else th.emplace_back(dedup_range, std::cref(A), std::cref(*par), std::cref(*regs), bases, read_offsets, r0, r1, std::ref(part[(size_t)t]), std::ref(cnt[(size_t)t]));
 	}
 	for (auto &t : th) t.join();
-	out_off.assign(1, 0); out_regs.clear(); out_ncomp.clear();
-	for (int t = 0; t < T; ++t) {
-		for (uint32_t k : cnt[(size_t)t]) out_off.push_back(out_off.back() + k);
-		for (const Reg &g : part[(size_t)t]) { out_regs.push_back(g.r); out_ncomp.push_back(g.n_comp); }
-	}
+	std::vector<size_t> rb((size_t)T + 1, 0);
+	for (int t = 0; t < T; ++t) rb[(size_t)t + 1] = rb[(size_t)t] + part[(size_t)t].size();
+	out_off.resize((size_t)n + 1); out_off[0] = 0; out_regs.resize(rb[(size_t)T]); out_ncomp.resize(rb[(size_t)T]);
+	auto join = [&](int t) { // every thread's share to where the prefix sums say
+		uint64_t o = rb[(size_t)t]; int64_t r = n * t / T;
+		for (uint32_t k : cnt[(size_t)t]) { o += k; out_off[(size_t)++r] = o; }
+		size_t i = rb[(size_t)t];
+		for (const Reg &g : part[(size_t)t]) { out_regs[i] = g.r; out_ncomp[i] = g.n_comp; ++i; }
+	};
+	if (T == 1) join(0);
+	else { std::vector<std::thread> tj; for (int t = 0; t < T; ++t) tj.emplace_back(join, t); for (auto &t : tj) t.join(); }
 	return CS_OK;
 }

@@ -63,12 +63,12 @@ ix = ca.Index.load(PREFIX); eng = ca.Engine(ix, 0); ch = ca.Chainer(PREFIX); al 
 out = {"reads": n, "reference": ("synthetic %g Mbp" % args.synth_mbp) if args.synth_mbp > 0 else "tests/golden/g1 (220 kbp, tandem arrays)"}
 for rep in range(2):   # the second round is the measured one (buffers sized)
     t0 = time.perf_counter(); res = eng.seed_batch(bases, off, ca.Params()); t1 = time.perf_counter()
-    c = ch.chain(res.mem_off, res.mems, res.seed_off, res.seeds, off, ca.ChainParams(), threads=16); t2 = time.perf_counter()
-    f = ch.filter(c["chain_off"], c["chains"], c["cseed_off"], c["cseeds"], bases, off, threads=16); t3 = time.perf_counter()
+    c = ch.chain(res.mem_off, res.mems, res.seed_off, res.seeds, off, ca.ChainParams(), threads=16, copy=False); t2 = time.perf_counter()
+    f = ch.filter(c["chain_off"], c["chains"], c["cseed_off"], c["cseeds"], bases, off, threads=16, copy=False); t3 = time.perf_counter()
     st0 = al.stats()
-    g = al.extend_chains(f["chain_off"], f["chains"], f["cseed_off"], f["cseeds"], bases, off, cseed_score=f["cseed_score"]); t4 = time.perf_counter()
+    g = al.extend_chains(f["chain_off"], f["chains"], f["cseed_off"], f["cseeds"], bases, off, cseed_score=f["cseed_score"], copy=False); t4 = time.perf_counter()
     st1 = al.stats()
-    d = al.dedup_regions(g["reg_off"], g["regs"], bases, off); t5 = time.perf_counter()
+    d = al.dedup_regions(g["reg_off"], g["regs"], bases, off, copy=False); t5 = time.perf_counter()
 for name, a, b in (("seed (host call)", t0, t1), ("chain", t1, t2), ("chain_filter", t2, t3), ("extend_chains", t3, t4), ("dedup_regions", t4, t5)):
     out[name] = {"ms": 1e3 * (b - a), "reads_per_s": n / (b - a)}
 out["counts"] = {"seeds": int(res.n_seeds), "chains": int(c["chains"].size), "chains_after_filter": int(f["chains"].size), "regions": int(g["regs"].size),
