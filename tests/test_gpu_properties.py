@@ -319,6 +319,19 @@ def test_full_baseline_size_properties():
             del first
         eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
         assert eng.result_digest() == d_on                                         # deterministic despite atomics / task order
+        # the same batch twice as a stream of device batches: both pass contexts run it AT THE SAME TIME and each must deliver the same 10 M results
+        eng.submit_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
+        eng.submit_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
+        eng.collect_device()
+        eng.submit_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))      # a third one beside the second: the first context again
+        eng.collect_device()
+        d1 = None
+        eng.collect_device(); d1 = eng.result_digest()                              # (the last result: held by the first context)
+        assert d1 == d_on, kw
+        eng.submit_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
+        eng.submit_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(**kw))
+        eng.collect_device(); eng.collect_device()
+        assert eng.result_digest() == d_on, kw                                      # ... and by the second
         eng.reset_stats()
         eng.seed_batch_device(bases.data_ptr(), off.data_ptr(), n, bases.numel(), ca.Params(sst_mode=0, **kw))
         st0 = eng.stats()
