@@ -337,11 +337,13 @@ int  cs_chain_filter(cs_chainer_t *c, const cs_flt_params_t *par, const cs_chain
  *      memory on the extender's GPU.  Pairs with qlen < 1, tlen < 0 or offsets outside the buffers get a zero result and the call returns
  *      CS_EINVAL after delivering the others. */
 typedef struct { int8_t mat[25]; int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus; uint32_t flags; } cs_ext_params_t;
-#define CS_EXT_PACKED16     1u   /* flags: queries longer than 64 bases go through the second kernel (two columns per lane, packed int16); exact, */
-#define CS_EXT_PACKED16_ALL 2u   /* ... all queries of the 16-bit class do.  Default 0: one column per lane for everything (faster on 150-bp reads)    */
+/* flags.  Default 0: queries of up to 160 columns whose scores fit 15 bits (every extension of a 150-bp read) run one pair per LANE, the rest
+ * one wavefront per pair, a query column per lane.  The others are A/B switches; every combination gives the same results. */
+#define CS_EXT_PACKED16     1u   /* wave-per-pair only, queries longer than 64 bases through a kernel with two columns per lane (packed int16); exact, slower */
+#define CS_EXT_PACKED16_ALL 2u   /* ... all queries of the 16-bit class through it */
 #define CS_EXT_NO_LANES     4u   /* do not use the one-pair-per-lane kernel for short queries (A/B tests): every pair goes one wave per pair */
 #define CS_EXT_LANES_QIN    8u   /* lane kernel, 8-bit class: the query base inside the score cell (one LDS read per cell, a third more LDS); exact; an experiment */
-typedef struct { uint64_t q_off, t_off; int32_t qlen, tlen, h0, reserved; } cs_ext_pair_t;
+typedef struct { uint64_t q_off, t_off; int32_t qlen, tlen, h0, reserved; } cs_ext_pair_t;   /* reserved: not looked at (the caller's own tag, e.g. the region a pair belongs to) */
 typedef struct { int32_t score, qle, tle, gtle, gscore, max_off; } cs_ext_result_t;
 typedef struct { uint64_t pairs, cells, rows, launches; double kernel_ms; } cs_ext_stats_t;   /* cells = DP cells computed (inside the adaptive band) */
 typedef struct cs_extender cs_extender_t;
