@@ -91,7 +91,7 @@ def test_against_the_oracle_on_random_pairs(qlo, qhi, n, par):
         pr = np.zeros(n, dtype=ca.EXT_PAIR_DT)
         for f in ("q_off", "t_off", "qlen", "tlen", "h0"):
             pr[f] = pairs[f]
-        for flags in (0, 1, 2):                              # one column per lane (default), the int16 kernel for long queries, for all
+        for flags in (0, 1, 2, 4, 8):                        # lane per pair (default), the int16 kernel for long queries / for all, wave per pair only, base in the cell
             P.flags = flags
             x = ca.Extender(0, P)
             got = x.extend(pr, qbuf, tbuf, w)
@@ -99,6 +99,40 @@ def test_against_the_oracle_on_random_pairs(qlo, qhi, n, par):
             x.close()
             assert np.array_equal(got, want.astype(ca.EXT_RES_DT)), (qlo, qhi, w, flags, int((got != want.astype(ca.EXT_RES_DT)).sum()))
             assert st["pairs"] == n and st["cells"] > 0 and st["rows"] > 0
+
+
+def test_score_width_classes_of_the_lane_kernel():
+    """the lane kernel keeps 8-bit scores where h0 + qlen x match <= 255 and 16-bit ones above: perfect matches whose score ends exactly at
+    250 .. 262 (both sides of the boundary), match scores 1 and 2, against the oracle; and queries of 158 .. 163 columns (the lane kernel
+    takes up to 160, the wave-per-pair kernel the rest)"""
+    import compseed_amd as ca
+    rng = np.random.default_rng(77)
+    for a, cases in ((1, [(h0, L) for L in (100, 149, 150, 158, 160, 161, 163) for h0 in range(250 - L, 263 - L) if h0 >= 0]),
+                     (2, [(h0, L) for L in (60, 100, 120) for h0 in range(250 - 2 * L, 263 - 2 * L) if h0 >= 0])):
+        n = len(cases)
+        pairs = np.zeros(n, dtype=_oracle.BSW_PAIR_DT)
+        qs, ts = [], []
+        qo = to = 0
+        for k, (h0, L) in enumerate(cases):
+            q = rng.integers(0, 4, L, dtype=np.uint8)
+            t = np.concatenate([q, rng.integers(0, 4, 40, dtype=np.uint8)])
+            pairs[k] = (qo, to, L, t.size, h0, 0)
+            qs.append(q); ts.append(t); qo += L; to += t.size
+        qbuf, tbuf = np.concatenate(qs), np.concatenate(ts)
+        mat = np.array([(-1 if (i == 4 or j == 4) else (a if i == j else -4)) for i in range(5) for j in range(5)], dtype=np.int8)
+        P = ca.ExtParams(mat=mat)
+        fx = dict(mat=mat, pairs=pairs, qbuf=qbuf, tbuf=tbuf, meta=np.tile(np.array([[0, 100, P.zdrop, P.end_bonus, P.o_del, P.e_del, P.o_ins, P.e_ins] + [0] * 9], dtype=np.int32), (n, 1)))
+        want = _oracle.bsw_extend(fx, threads=2).astype(ca.EXT_RES_DT)
+        assert (want["score"] >= 250).all() and (want["score"] > 255).any() and (want["score"] <= 255).any()
+        pr = np.zeros(n, dtype=ca.EXT_PAIR_DT)
+        for f in ("q_off", "t_off", "qlen", "tlen", "h0"):
+            pr[f] = pairs[f]
+        for flags in (0, 4, 8):
+            P.flags = flags
+            x = ca.Extender(0, P)
+            got = x.extend(pr, qbuf, tbuf, 100)
+            x.close()
+            assert np.array_equal(got, want), (a, flags, int((got != want).sum()))
 
 
 def test_device_variant_and_errors():
