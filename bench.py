@@ -622,6 +622,16 @@ def main():
         except Exception as ex:  # noqa: BLE001
             log("extension side measurement failed: %r" % (ex,))
             out["extension"] = {"error": repr(ex)[:300]}
+        # ... and the stages behind seeding as a whole (tools/align_bench.py): 1 M reads against a synthetic 200 Mbp genome indexed from FASTA
+        # on the GPU, through cs_chain_batch -> cs_chain_filter -> cs_extend_chains -> cs_dedup_regions; wall time per library call
+        try:
+            import align_bench
+            torch.cuda.empty_cache()
+            out["extension"]["stage"] = align_bench.run(1000000, 200.0)
+        except Exception as ex:  # noqa: BLE001
+            log("alignment stage side measurement failed: %r" % (ex,))
+            if isinstance(out.get("extension"), dict):
+                out["extension"]["stage"] = {"error": repr(ex)[:300]}
     side = [w for w in args.side_workloads.split(",") if w and w != args.profile]
     if rank == 0 and world == 1 and side and not args.side_child and not args.pmc_child:
         # ---- the same measurement on other workload profiles (tools/synth.py), outside the headline: a child run of this script per
