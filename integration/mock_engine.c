@@ -75,3 +75,20 @@ int cs_engine_collect_packed(cs_engine_t *e, cs_packed_result_t *out)
 	e->st.reads += (uint64_t)e->q[k].n; e->st.mems += st.n_mems; e->st.seeds += st.n_seeds; e->st.bwt_queries += st.bwt_queries; e->st.bwt_calls += st.bwt_calls;
 	return CS_OK;
 }
+
+/* the extension stage has no CPU stand-in here: the patched reference then keeps its own mem_chain2aln_across_reads_V2 */
+void cs_aln_params_default(cs_aln_params_t *p) { if (p) memset(p, 0, sizeof *p); }
+int cs_aligner_create(const char *prefix, int device, const cs_aln_params_t *par, cs_aligner_t **out)
+{
+	(void)prefix; (void)device; (void)par;
+	if (out) *out = NULL;
+	g_err = "the mock has no extension stage";
+	return CS_EDEVICE;
+}
+void cs_aligner_destroy(cs_aligner_t *a) { (void)a; }
+int cs_extend_chains(cs_aligner_t *a, const cs_chain_result_t *chains, const int32_t *cseed_score, const uint8_t *bases, const uint64_t *read_offsets, cs_aln_result_t *out)
+{
+	(void)a; (void)chains; (void)cseed_score; (void)bases; (void)read_offsets; (void)out;
+	g_err = "the mock has no extension stage";
+	return CS_EDEVICE;
+}
