@@ -92,3 +92,15 @@ int cs_extend_chains(cs_aligner_t *a, const cs_chain_result_t *chains, const int
 	g_err = "the mock has no extension stage";
 	return CS_EDEVICE;
 }
+/* (never reached with the mock: cs_aligner_create fails, so the patched reference keeps its own chaining, filters and de-duplication) */
+int cs_chainer_create(const char *prefix, cs_chainer_t **out) { (void)prefix; if (out) *out = NULL; g_err = "the mock has no chainer"; return CS_EDEVICE; }
+void cs_chainer_destroy(cs_chainer_t *c) { (void)c; }
+void cs_chain_params_default(cs_chain_params_t *p) { if (p) memset(p, 0, sizeof *p); }
+void cs_flt_params_default(cs_flt_params_t *p) { if (p) memset(p, 0, sizeof *p); }
+void cs_dedup_params_default(cs_dedup_params_t *p) { if (p) memset(p, 0, sizeof *p); }
+int cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, const cs_result_t *seeds, const uint64_t *read_offsets, int n_threads, cs_chain_result_t *out)
+{ (void)c; (void)par; (void)seeds; (void)read_offsets; (void)n_threads; (void)out; return CS_EDEVICE; }
+int cs_chain_filter(cs_chainer_t *c, const cs_flt_params_t *par, const cs_chain_result_t *in, const uint8_t *bases, const uint64_t *read_offsets, int n_threads, cs_chain_result_t *out, const int32_t **cseed_score)
+{ (void)c; (void)par; (void)in; (void)bases; (void)read_offsets; (void)n_threads; (void)out; (void)cseed_score; return CS_EDEVICE; }
+int cs_dedup_regions(cs_aligner_t *a, const cs_dedup_params_t *par, const cs_aln_result_t *regs, const uint8_t *bases, const uint64_t *read_offsets, cs_aln_result_t *out, const int32_t **n_comp)
+{ (void)a; (void)par; (void)regs; (void)bases; (void)read_offsets; (void)out; (void)n_comp; return CS_EDEVICE; }
