@@ -609,29 +609,6 @@ def main():
         del big, g_
     oidx.close()
     eng.close(); ix.close()
-    if rank == 0 and world == 1 and not args.side_child and not args.pmc_child and not args.no_extension:
-        # ---- SURVEY 8f row 4, the stage behind seeding + chaining: banded Smith-Waterman seed extension on the GPU (tools/extend_bench.py);
-        # integer-compute-bound, so pairs/s and DP cells/s, not a fraction of HBM bandwidth; never part of `value`
-        try:
-            import extend_bench
-            out["extension"] = extend_bench.run(cpu_threads=min(16, cpu_quota()[0]), device=local)
-            if not out["extension"]["bit_exact_vs_oracle"]:
-                all_ok = False
-                out["value"] = None
-                out["error"] = "extension kernel: results differ from the oracle"
-        except Exception as ex:  # noqa: BLE001
-            log("extension side measurement failed: %r" % (ex,))
-            out["extension"] = {"error": repr(ex)[:300]}
-        # ... and the stages behind seeding as a whole (tools/align_bench.py): 1 M reads against a synthetic 200 Mbp genome indexed from FASTA
-        # on the GPU, through cs_chain_batch -> cs_chain_filter -> cs_extend_chains -> cs_dedup_regions; wall time per library call
-        try:
-            import align_bench
-            torch.cuda.empty_cache()
-            out["extension"]["stage"] = align_bench.run(1000000, 200.0)
-        except Exception as ex:  # noqa: BLE001
-            log("alignment stage side measurement failed: %r" % (ex,))
-            if isinstance(out.get("extension"), dict):
-                out["extension"]["stage"] = {"error": repr(ex)[:300]}
     side = [w for w in args.side_workloads.split(",") if w and w != args.profile]
     if rank == 0 and world == 1 and side and not args.side_child and not args.pmc_child:
         # ---- the same measurement on other workload profiles (tools/synth.py), outside the headline: a child run of this script per
@@ -661,6 +638,31 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 log("side workload %s failed: %r" % (w, ex))
                 out["workloads"][w] = {"error": repr(ex)[:300]}
+    # (the extension measurements come after the side workloads: what they leave allocated in this process cost the children's engines an
+    # optional array -- repeat50 ran at 139 instead of 110 ms per stage)
+    if rank == 0 and world == 1 and not args.side_child and not args.pmc_child and not args.no_extension:
+        # ---- SURVEY 8f row 4, the stage behind seeding + chaining: banded Smith-Waterman seed extension on the GPU (tools/extend_bench.py);
+        # integer-compute-bound, so pairs/s and DP cells/s, not a fraction of HBM bandwidth; never part of `value`
+        try:
+            import extend_bench
+            out["extension"] = extend_bench.run(cpu_threads=min(16, cpu_quota()[0]), device=local)
+            if not out["extension"]["bit_exact_vs_oracle"]:
+                all_ok = False
+                out["value"] = None
+                out["error"] = "extension kernel: results differ from the oracle"
+        except Exception as ex:  # noqa: BLE001
+            log("extension side measurement failed: %r" % (ex,))
+            out["extension"] = {"error": repr(ex)[:300]}
+        # ... and the stages behind seeding as a whole (tools/align_bench.py): 1 M reads against a synthetic 200 Mbp genome indexed from FASTA
+        # on the GPU, through cs_chain_batch -> cs_chain_filter -> cs_extend_chains -> cs_dedup_regions; wall time per library call
+        try:
+            import align_bench
+            torch.cuda.empty_cache()
+            out["extension"]["stage"] = align_bench.run(1000000, 200.0)
+        except Exception as ex:  # noqa: BLE001
+            log("alignment stage side measurement failed: %r" % (ex,))
+            if isinstance(out.get("extension"), dict):
+                out["extension"]["stage"] = {"error": repr(ex)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)   # the ONE line
     D.close()
