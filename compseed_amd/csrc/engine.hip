@@ -57,7 +57,7 @@ extern "C" void cs_engine_options_default(cs_engine_options_t *o)
 	if (!o) return;
 	memset(o, 0, sizeof *o);
 	o->full_sa = 1; o->sa64 = 0; o->text_mode = 1; o->text_arrays = 1; o->jump_k = 15; o->kmer_filter = 1; o->fused = 0;
-	o->mem_cap = 64; o->lep_arena_mb = 16384; o->max_raw_mb = 24576; o->r3_text_iter = 4; o->count_sal_merged = 0; o->verbose = 0;
+	o->mem_cap = 64; o->lep_arena_mb = 16384; o->max_raw_mb = 24576; o->r3_text_iter = 5; o->count_sal_merged = 0; o->verbose = 0;
 	o->pipeline_reads = 5000000; o->expand_threads = 16; o->host_pack_threads = 8; o->passes_in_flight = 2;
 }
 
@@ -852,7 +852,7 @@ static int run_smem_split_body(cs_engine *e, const cs_params_t *par, const uint6
 	if (r3_async && r3_after <= 0) { CS_TRY(launch_r3()); r3_launched = true; }
 	// r3text_kernel runs on the second stream beside the late iterations (from the 5th on they carry < 2 % of the tasks but
 	// still cost a launch chain and a host round trip each); it works from a snapshot of the mem counts
-	const int r3t_iter = e->opt.r3_text_iter; // measured in round 2, one pass at a time: 2: 67.8, 3: 66.9, 4: 66.0, 5: 66.8, 6: 68.0 ms; with two passes in flight (round 3): 4: 47.6, 5: 47.0, 6: 47.0 ms per step, one at a time 54.6 / 54.6 / 55.7 -- but 5 costs the repeat-rich workload a quarter of its stage time (110 -> 150 ms: its iterations are long, round 3 then ends after them), so 4 stays
+	const int r3t_iter = e->opt.r3_text_iter; // measured in round 2, one pass at a time: 2: 67.8, 3: 66.9, 4: 66.0, 5: 66.8, 6: 68.0 ms; with two passes in flight (round 3): 4: 47.6, 5: 47.0, 6: 47.0 ms per step, one at a time 54.6 / 54.6 / 55.7; repeat50: 4 and 5 the same (110.8 / 111.1 ms per step)
 	bool r3t_launched = false;
 	if (r3_text) { CS_TRY(e->d_cnt_snap.reserve((size_t)nb + 1)); CS_TRY(e->d_pending.reserve((size_t)nb + 1)); }
 	auto launch_r3text = [&](const uint64_t *queue, const unsigned long long *queue_n) -> int {

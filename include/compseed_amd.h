@@ -90,7 +90,7 @@ typedef struct {
 	int32_t mem_cap;          /* [64] mems per read held in the first-pass arena (more go through the overflow records)       */
 	int64_t lep_arena_mb;     /* [16384] arena of the forward passes' left-extension points, per pass context; smaller = more chunks per pass */
 	int64_t max_raw_mb;       /* [24576] first-pass mem arena; smaller = a batch is processed in more sub-batches             */
-	int32_t r3_text_iter;     /* [4] forward launch after which round 3 starts on its side stream                             */
+	int32_t r3_text_iter;     /* [5] forward launch after which round 3 starts on its side stream                             */
 	int32_t pipeline_reads;   /* [5000000] reads per sub-batch of the host variants (cs_engine_seed_batch, _packed): upload of the next,
 	                           *     seeding of the current and download of the previous sub-batch overlap; 0 = the whole batch at once */
 	int32_t expand_threads;   /* [16] host threads that expand packed results in cs_engine_seed_batch                         */
