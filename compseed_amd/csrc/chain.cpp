@@ -80,7 +80,7 @@ struct Tree { // node 0 is the root until it splits; nodes live in a vector that
 			int r, i = locate(nd[x], k, r);
 			if (!nd[x].internal) {
 				Node &X = nd[x];
-				if (i != X.n - 1) { memmove(X.pos + i + 2, X.pos + i + 1, sizeof(int64_t) * (X.n - i - 1)); memmove(X.id + i + 2, X.id + i + 1, sizeof(int32_t) * (X.n - i - 1)); }
+				if (i != X.n - 1) { memmove(&X.pos[i + 2], &X.pos[i + 1], sizeof(int64_t) * (X.n - i - 1)); memmove(&X.id[i + 2], &X.id[i + 1], sizeof(int32_t) * (X.n - i - 1)); } // (i may be -1)
 				X.pos[i + 1] = k; X.id[i + 1] = id; ++X.n;
 				return;
 			}

@@ -134,7 +134,7 @@ void filter_range(const cs_chainer &C, const cs_flt_params_t &o, const cs_chain_
 		}
 		// ---- mem_flt_chained_seeds
 		const double min_l = o.min_chain_weight ? 1.1f * (float)o.min_chain_weight : 5.5f * std::log((double)l_query);   // MEM_HSP_COEF, MEM_MINSC_COEF
-		const int min_hsp = (int)(o.a * min_l + .499);
+		const int min_hsp = (l_query > 0 || o.min_chain_weight) ? (int)(o.a * min_l + .499) : 0;                         // (an empty read has no chains; log(0) must not reach the conversion)
 		const bool seed_sw = !(min_l > 0.05f * (float)l_query) && l_query > 0;                                          // MEM_SEEDSW_COEF: not for short reads
 		if (seed_sw) { query.resize((size_t)l_query); for (int j = 0; j < l_query; ++j) query[(size_t)j] = cs_base_code_(bases[read_off[r] + (uint64_t)j]); }
 		for (int idx : order) {
