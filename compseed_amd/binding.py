@@ -158,10 +158,10 @@ ALNREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4")
 
 class AlnParams(C.Structure):
     """cs_aln_params_t: the mem_opt_t fields the extension stage reads (-A -B -O -E -L -w -d)"""
-    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "zdrop", "threads")]
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "zdrop", "threads")] + [("flags", C.c_uint32)]
 
-    def __init__(self, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, pen_clip5=5, pen_clip3=5, w=100, zdrop=100, threads=8):
-        super().__init__(a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop, threads)
+    def __init__(self, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, pen_clip5=5, pen_clip3=5, w=100, zdrop=100, threads=16, flags=0):
+        super().__init__(a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop, threads, flags)
 
 
 class CAlnResult(C.Structure):

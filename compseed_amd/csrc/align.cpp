@@ -30,7 +30,7 @@ extern "C" void cs_aln_params_default(cs_aln_params_t *p)
 	if (!p) return;
 	// mem_opt_init (comp_seed.cpp:26-58)
 	p->a = 1; p->b = 4; p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1; p->pen_clip5 = p->pen_clip3 = 5; p->w = 100; p->zdrop = 100;
-	p->threads = 16;
+	p->threads = 16; p->flags = 0;
 }
 
 extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_params_t *par, cs_aligner_t **out)
@@ -40,7 +40,7 @@ extern "C" int cs_aligner_create(const char *prefix, int device, const cs_aln_pa
 	cs_aligner *A = new cs_aligner();
 	if (par) A->par = *par; else cs_aln_params_default(&A->par);
 	const cs_aln_params_t &o = A->par;
-	if (o.a < 1 || o.b < 0 || o.e_del < 1 || o.e_ins < 1 || o.o_del < 0 || o.o_ins < 0 || o.w < 1 || o.zdrop < 0) { delete A; return cs_fail_(CS_EINVAL, "cs_aligner_create: bad scoring parameters"); }
+	if (o.a < 1 || o.b < 0 || o.e_del < 1 || o.e_ins < 1 || o.o_del < 0 || o.o_ins < 0 || o.w < 1 || o.zdrop < 0 || (o.flags & ~(CS_ALN_NO_LIGHT_PATHS | CS_ALN_PURGE_FROM_HBM))) { delete A; return cs_fail_(CS_EINVAL, "cs_aligner_create: bad scoring parameters or unknown flags"); }
 	int rc = cs_load_contigs_(prefix, A->ref);
 	if (rc != CS_OK) { delete A; return rc; }
 	rc = cs_load_pac_(prefix, A->ref.l_pac, A->pac);

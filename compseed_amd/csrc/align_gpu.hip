@@ -45,7 +45,9 @@ struct Args {
 	uint32_t *chain_read; int64_t *w0; uint64_t *wlen2, *tb0;   // per chain: window start, 2 x length (scanned into tb0)
 	uint8_t *qbuf, *tbuf; uint32_t *ord; cs_alnreg_t *regs; uint32_t *reg_ci;
 	cs_ext_pair_t *lp, *rp;
-	unsigned long long *ctr;               // [0] left pairs [1] right pairs [2] retries [3] bad chains [4] purged
+	int32_t small_chain, light_max, purge_cap;   // SMALL_CHAIN / 64 / PURGE_CAP unless cs_aln_params_t.flags says otherwise (A/B tests)
+	uint32_t *big, *big_reads;             // chains of more than SMALL_CHAIN seeds / reads of more than 64 regions: lists for the *_big kernels
+	unsigned long long *ctr;               // [0] left pairs [1] right pairs [2] retries [3] bad chains [4] purged [5] long chains [6] long reads
 };
 
 __device__ __forceinline__ int affordable_gap(const cs_aln_params_t &o, int qlen) // cal_max_gap (comp_seed.cpp:415-421)
@@ -127,52 +129,114 @@ __global__ void fill_kernel(const Args A)
 		}
 	}
 }
-__global__ void region_kernel(const Args A)
+// ---- regions.  A chain's seeds are extended in the order of their scores, highest first, later ones first among equals (comp_seed.cpp:1406-1411);
+// that order is total, so a seed's place is the number of seeds that rank before it and every seed can be placed on its own.
+constexpr int SMALL_CHAIN = 8;
+__device__ __forceinline__ int seed_rank(const cs_seed_t *sd, const int32_t *sc, int ns, int i)
+{
+	const int si = sc ? sc[i] : sd[i].len;
+	int rk = 0;
+	for (int y = 0; y < ns; ++y) { const int sy = sc ? sc[y] : sd[y].len; rk += (sy > si || (sy == si && y > i)) ? 1 : 0; }
+	return rk;
+}
+struct ChainCtx { int64_t ci, w0, L, tb0; uint64_t s0, rb0; int32_t l_query, rid, chain; float frac_rep; };
+__device__ __forceinline__ ChainCtx chain_ctx(const Args &A, int64_t ci)
+{
+	ChainCtx X;
+	const cs_chain_t c = A.chains[ci];
+	const uint32_t r = A.chain_read[ci];
+	X.ci = ci; X.s0 = A.cseed_off[ci]; X.rb0 = A.read_off[r]; X.l_query = (int32_t)(A.read_off[r + 1] - X.rb0);
+	X.w0 = A.w0[ci]; X.L = (int64_t)(A.wlen2[ci] >> 1); X.tb0 = (int64_t)A.tb0[ci];
+	X.rid = c.rid; X.frac_rep = c.frac_rep; X.chain = (int32_t)(ci - (int64_t)A.chain_off[r]);
+	return X;
+}
+// seed i of the chain, k-th in the order of extension: its region and its (at most two) pairs, at the slots the caller reserved
+__device__ __forceinline__ void emit_region(const Args &A, const ChainCtx &X, const cs_seed_t &s, int i, int k, bool left, bool right, uint64_t lslot, uint64_t rslot)
 {
 	const cs_aln_params_t &o = A.o;
-	for (int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < A.n_chains; ci += (int64_t)gridDim.x * blockDim.x) {
-		const uint64_t s0 = A.cseed_off[ci];
-		const cs_seed_t *sd = A.cseeds + s0;
-		const int32_t *sc = A.score ? A.score + s0 : nullptr;
-		const int ns = (int)(A.cseed_off[ci + 1] - s0);
-		if (ns <= 0) continue;
-		const cs_chain_t c = A.chains[ci];
-		const uint32_t r = A.chain_read[ci];
-		const uint64_t rb0 = A.read_off[r];
-		const int l_query = (int)(A.read_off[r + 1] - rb0);
-		const int64_t w0 = A.w0[ci], L = (int64_t)(A.wlen2[ci] >> 1), tb0 = (int64_t)A.tb0[ci];
-		uint32_t *ord = A.ord + s0;
-		// seeds by score, highest first, later ones first among equals: insertion sort (chains have a handful of seeds, rarely hundreds)
-		for (int i = 0; i < ns; ++i) {
-			const int si = sc ? sc[i] : sd[i].len;
-			int k = i;
-			while (k > 0) {
-				const uint32_t y = ord[k - 1];
-				const int sy = sc ? sc[y] : sd[y].len;
-				if (sy > si || (sy == si && (int)y > i)) break;        // y ranks before i
-				ord[k] = y; --k;
+	const uint64_t g = X.s0 + (uint64_t)k;
+	cs_alnreg_t a; memset(&a, 0, sizeof a);
+	a.w = o.w; a.score = a.truesc = -1; a.rid = X.rid; a.frac_rep = X.frac_rep; a.seedlen0 = s.len; a.chain = X.chain;
+	a.rb = a.re = UNSET; a.qb = a.qe = UNSET;
+	if (left) { // reversed read prefix against the reversed window in front of the seed
+		const int64_t tl = s.rbeg - X.w0;
+		const cs_ext_pair_t p = {(uint64_t)(A.n_bases + X.rb0 + (uint64_t)(X.l_query - s.qbeg)), (uint64_t)(X.tb0 + X.L + (X.L - tl)), s.qbeg, (int32_t)tl, s.len * o.a, (int32_t)g};
+		A.lp[lslot] = p;
+		a.qb = s.qbeg; a.rb = s.rbeg;
+	} else { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; }
+	if (right) { // the rest of the read against the window behind the seed
+		const int qe = s.qbeg + s.len; const int64_t re = s.rbeg + s.len - X.w0;
+		const cs_ext_pair_t p = {(uint64_t)(X.rb0 + (uint64_t)qe), (uint64_t)(X.tb0 + re), X.l_query - qe, (int32_t)(X.L - re), 0, (int32_t)g};
+		A.rp[rslot] = p;
+		a.qe = qe; a.re = X.w0 + re;
+	} else { a.qe = X.l_query; a.re = s.rbeg + s.len; }
+	A.regs[g] = a; A.reg_ci[g] = (uint32_t)X.ci; A.ord[g] = (uint32_t)i;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t &total)
+{
+	uint32_t x = v;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+	total = __shfl(x, 63);
+	return x - v;
+}
+// a chain per lane for the chains of up to SMALL_CHAIN seeds (nearly all); the pair slots of a wave's 64 chains come from one atomic per
+// side (one per pair made the two counters the kernel's clock); longer chains go on a list for region_big_kernel
+__global__ void region_kernel(const Args A)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < A.n_chains; base += stride) {
+		const int64_t ci = base + lane;
+		int ns = 0; bool mine = false; uint32_t nl = 0, nr = 0;
+		ChainCtx X; const cs_seed_t *sd = nullptr;
+		if (ci < A.n_chains) {
+			const uint64_t s0 = A.cseed_off[ci];
+			ns = (int)(A.cseed_off[ci + 1] - s0);
+			if (ns > A.small_chain) A.big[atomicAdd(A.ctr + 5, 1ull)] = (uint32_t)ci;
+			else if (ns > 0) {
+				mine = true; X = chain_ctx(A, ci); sd = A.cseeds + s0;
+				for (int i = 0; i < ns; ++i) { const cs_seed_t s = sd[i]; nl += s.qbeg != 0; nr += s.qbeg + s.len != X.l_query; }
 			}
-			ord[k] = (uint32_t)i;
 		}
-		for (int k = 0; k < ns; ++k) {
-			const cs_seed_t s = sd[ord[k]];
-			const uint64_t g = s0 + (uint64_t)k;
-			cs_alnreg_t a; memset(&a, 0, sizeof a);
-			a.w = o.w; a.score = a.truesc = -1; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = (int32_t)(ci - (int64_t)A.chain_off[r]);
-			a.rb = a.re = UNSET; a.qb = a.qe = UNSET;
-			if (s.qbeg) { // left: reversed read prefix against the reversed window in front of the seed
-				const int64_t tl = s.rbeg - w0;
-				const cs_ext_pair_t p = {(uint64_t)(A.n_bases + rb0 + (uint64_t)(l_query - s.qbeg)), (uint64_t)(tb0 + L + (L - tl)), s.qbeg, (int32_t)tl, s.len * o.a, (int32_t)g};
-				A.lp[atomicAdd(A.ctr + 0, 1ull)] = p;
-				a.qb = s.qbeg; a.rb = s.rbeg;
-			} else { a.score = a.truesc = s.len * o.a; a.qb = 0; a.rb = s.rbeg; }
-			if (s.qbeg + s.len != l_query) { // right: the rest of the read against the window behind the seed
-				const int qe = s.qbeg + s.len; const int64_t re = s.rbeg + s.len - w0;
-				const cs_ext_pair_t p = {(uint64_t)(rb0 + (uint64_t)qe), (uint64_t)(tb0 + re), l_query - qe, (int32_t)(L - re), 0, (int32_t)g};
-				A.rp[atomicAdd(A.ctr + 1, 1ull)] = p;
-				a.qe = qe; a.re = w0 + re;
-			} else { a.qe = l_query; a.re = s.rbeg + s.len; }
-			A.regs[g] = a; A.reg_ci[g] = (uint32_t)ci;
+		uint32_t tl, tr;
+		const uint32_t el = wave_excl_scan(nl, lane, tl), er = wave_excl_scan(nr, lane, tr);
+		unsigned long long bl = 0, br = 0;
+		if (lane == 0) { if (tl) bl = atomicAdd(A.ctr + 0, (unsigned long long)tl); if (tr) br = atomicAdd(A.ctr + 1, (unsigned long long)tr); }
+		bl = __shfl(bl, 0); br = __shfl(br, 0);
+		if (mine) {
+			uint64_t ls = bl + el, rs = br + er;
+			const int32_t *sc = A.score ? A.score + X.s0 : nullptr;
+			for (int i = 0; i < ns; ++i) {
+				const cs_seed_t s = sd[i];
+				const bool left = s.qbeg != 0, right = s.qbeg + s.len != X.l_query;
+				emit_region(A, X, s, i, seed_rank(sd, sc, ns, i), left, right, ls, rs);
+				ls += left; rs += right;
+			}
+		}
+	}
+}
+// one wave per long chain (a repeat's hundreds of seeds on one diagonal band): a seed per lane, 64 at a time
+__global__ void region_big_kernel(const Args A)
+{
+	const int lane = threadIdx.x & 63;
+	const uint64_t lt = (1ull << lane) - 1ull;
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	const uint64_t n_big = A.ctr[5];
+	for (uint64_t e = wave; e < n_big; e += n_waves) {
+		const int64_t ci = (int64_t)A.big[e];
+		const ChainCtx X = chain_ctx(A, ci);
+		const cs_seed_t *sd = A.cseeds + X.s0;
+		const int32_t *sc = A.score ? A.score + X.s0 : nullptr;
+		const int ns = (int)(A.cseed_off[ci + 1] - X.s0);
+		for (int i0 = 0; i0 < ns; i0 += 64) {
+			const int i = i0 + lane;
+			cs_seed_t s = {0, 0, 0}; int k = 0; bool left = false, right = false;
+			if (i < ns) { s = sd[i]; k = seed_rank(sd, sc, ns, i); left = s.qbeg != 0; right = s.qbeg + s.len != X.l_query; }
+			const uint64_t ml = __ballot(left), mr = __ballot(right);
+			unsigned long long bl = 0, br = 0;
+			if (lane == 0) { if (ml) bl = atomicAdd(A.ctr + 0, (unsigned long long)__popcll(ml)); if (mr) br = atomicAdd(A.ctr + 1, (unsigned long long)__popcll(mr)); }
+			bl = __shfl(bl, 0); br = __shfl(br, 0);
+			if (i < ns) emit_region(A, X, s, i, k, left, right, bl + (uint64_t)__popcll(ml & lt), br + (uint64_t)__popcll(mr & lt));
 		}
 	}
 }
@@ -220,66 +284,149 @@ __global__ void seedcov_kernel(const Args A) // the chain's seeds that lie insid
 // comp_seed.cpp:2141-2232: walking a read's seeds in the order they were extended, a seed that lies inside an earlier, surviving region of
 // the read, is not much longer than that region's seed and sits within the band of its diagonal at either end is redundant -- unless a
 // higher-ranked seed of its chain that is still in play overlaps it on another diagonal.  Its region is marked qb = qe = -1.
-// One WAVE per read: the walk over the read's regions is sequential (a region's fate decides about the later ones), but both tests are
-// "is there one among the earlier ...", so the lanes take the earlier regions / the higher-ranked seeds 64 at a time and a ballot answers.
-// (One thread per read took 1.5 s for 400,000 reads with 68 regions each; this takes a few ms.)  Which regions are purged so far is kept
-// in a byte array that is read around the L1 (volatile): lane 0 writes, the whole wave reads in the next step.
-__global__ void purge_kernel(const Args A, uint8_t *pflag)
+// The walk over a read's regions is sequential (a region's fate decides about the later ones), but both tests are "is there one among
+// the earlier ...": the lanes of a wave hold the earlier regions / the higher-ranked seeds and a ballot answers.
+struct PReg { int64_t rb, re; int32_t qb, qe, seedlen0, w; };
+template <class GapF> // gap_of(x) = affordable_gap(o, x); x is a distance inside the read here, 0 .. l_query
+__device__ __forceinline__ bool purge_around(const cs_seed_t &s, const PReg &p, int l_query, GapF gap_of)
+{
+	if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) return false;
+	if (s.len - p.seedlen0 > .1 * l_query) return false;
+	int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
+	int gap = gap_of((int)(qd < rd ? qd : rd)), w = gap < p.w ? gap : p.w;
+	if (qd - rd < w && rd - qd < w) return true;
+	qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+	gap = gap_of((int)(qd < rd ? qd : rd)); w = gap < p.w ? gap : p.w;
+	return qd - rd < w && rd - qd < w;
+}
+__device__ __forceinline__ bool purge_rival(const cs_seed_t &s, const cs_seed_t &t) // t: a seed ranked above s in its chain
+{
+	if (t.len < s.len * .95) return false;
+	if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) return true;
+	return t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg;
+}
+__device__ __forceinline__ void purge_load(const Args &A, uint64_t g0, uint64_t g, PReg &p, cs_seed_t &s, int &first)
+{
+	const uint64_t s0 = A.cseed_off[A.reg_ci[g]];
+	first = (int)(s0 - g0);                                         // the read's regions [first, g) are the higher-ranked seeds of g's chain
+	s = A.cseeds[s0 + A.ord[g]];
+	const cs_alnreg_t a = A.regs[g];
+	p.rb = a.rb; p.re = a.re; p.qb = a.qb; p.qe = a.qe; p.seedlen0 = a.seedlen0; p.w = a.w;
+}
+// reads of up to 64 regions (all but a few in a thousand): a wave per read, a region per lane, everything in registers -- the seed in
+// question comes from its lane by a shuffle, which regions are still there is a mask.  Longer reads go on a list for purge_big_kernel.
+__global__ void purge_kernel(const Args A)
 {
 	const cs_aln_params_t &o = A.o;
-	volatile uint8_t *pf = pflag;
 	const int lane = threadIdx.x & 63;
 	const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 	unsigned long long my = 0;
 	for (int64_t r = wave; r < A.n_reads; r += n_waves) {
-		const int l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
-		const uint64_t g0 = A.cseed_off[A.chain_off[r]];
-		uint64_t g = g0;
-		for (uint64_t ci = A.chain_off[r]; ci < A.chain_off[r + 1]; ++ci) {
-			const uint64_t s0 = A.cseed_off[ci];
-			const cs_seed_t *sd = A.cseeds + s0;
-			const uint32_t *ord = A.ord + s0;
-			const int ns = (int)(A.cseed_off[ci + 1] - s0);
-			for (int k = 0; k < ns; ++k, ++g) {
-				const cs_seed_t s = sd[ord[k]];
-				bool around = false;
-				for (uint64_t base = g0; base < g && !around; base += 64) { // the earlier regions of the read that survive
-					const uint64_t i = base + (uint64_t)lane;
-					bool hit = false;
-					if (i < g && !pf[i]) {
-						const cs_alnreg_t p = A.regs[i];
-						if (!(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) && !(s.len - p.seedlen0 > .1 * l_query)) {
-							int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
-							int gap = affordable_gap(o, (int)(qd < rd ? qd : rd)), w = gap < p.w ? gap : p.w;
-							if (qd - rd < w && rd - qd < w) hit = true;
-							else {
-								qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-								gap = affordable_gap(o, (int)(qd < rd ? qd : rd)); w = gap < p.w ? gap : p.w;
-								if (qd - rd < w && rd - qd < w) hit = true;
-							}
-						}
-					}
-					around = __ballot(hit) != 0;
-				}
-				if (!around) continue;
-				bool rival = false;
-				for (int base = 0; base < k && !rival; base += 64) { // seeds ranked above this one that are still in play
-					const int v = base + lane;
-					bool hit = false;
-					if (v < k && !pf[s0 + (uint64_t)v]) {
-						const cs_seed_t t = sd[ord[v]];
-						if (!(t.len < s.len * .95)) {
-							if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) hit = true;
-							else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
-						}
-					}
-					rival = __ballot(hit) != 0;
-				}
-				if (rival) continue;
-				if (lane == 0) { pf[g] = 1; A.regs[g].qb = -1; A.regs[g].qe = -1; ++my; }
-				__threadfence();
-			}
+		const uint64_t g0 = A.cseed_off[A.chain_off[r]], g1 = A.cseed_off[A.chain_off[r + 1]];
+		if (g1 - g0 < 2) continue;                                  // (a read's first region has nothing in front of it)
+		if (g1 - g0 > (uint64_t)A.light_max) { if (lane == 0) A.big_reads[atomicAdd(A.ctr + 6, 1ull)] = (uint32_t)r; continue; }
+		const int G = (int)(g1 - g0), l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
+		PReg p = {0, 0, 0, 0, 0, 0}; cs_seed_t s = {0, 0, 0}; int first = 0;
+		if (lane < G) purge_load(A, g0, g0 + (uint64_t)lane, p, s, first);
+		const uint64_t all = G == 64 ? ~0ull : (1ull << G) - 1ull;
+		uint64_t alive = all;
+		for (int g = 1; g < G; ++g) {
+			cs_seed_t sg; sg.rbeg = (int64_t)__shfl((long long)s.rbeg, g); sg.qbeg = __shfl(s.qbeg, g); sg.len = __shfl(s.len, g);
+			const int fg = __shfl(first, g);
+			const bool before = lane < g && ((alive >> lane) & 1ull);
+			if (__ballot(before && purge_around(sg, p, l_query, [&](int x) { return affordable_gap(o, x); })) == 0) continue;
+			if (__ballot(before && lane >= fg && purge_rival(sg, s)) != 0) continue;
+			alive &= ~(1ull << g);
 		}
+		const uint64_t gone = all & ~alive;
+		if ((gone >> lane) & 1ull) { A.regs[g0 + (uint64_t)lane].qb = -1; A.regs[g0 + (uint64_t)lane].qe = -1; }
+		if (lane == 0) my += (unsigned long long)__popcll(gone);
+	}
+	if (lane == 0 && my) atomicAdd(A.ctr + 4, my);
+}
+// a read of any size straight from HBM (the fallback of purge_big_kernel): which regions are purged so far is a byte array that is read
+// around the L1 (volatile) -- lane 0 writes, the whole wave reads in the next step.  Every step is a chain of HBM round trips.
+__device__ void purge_read_global(const Args &A, int64_t r, uint8_t *pflag, int lane, unsigned long long &my)
+{
+	const cs_aln_params_t &o = A.o;
+	volatile uint8_t *pf = pflag;
+	const int l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
+	const uint64_t g0 = A.cseed_off[A.chain_off[r]];
+	uint64_t g = g0;
+	for (uint64_t ci = A.chain_off[r]; ci < A.chain_off[r + 1]; ++ci) {
+		const uint64_t s0 = A.cseed_off[ci];
+		const cs_seed_t *sd = A.cseeds + s0;
+		const uint32_t *ord = A.ord + s0;
+		const int ns = (int)(A.cseed_off[ci + 1] - s0);
+		for (int k = 0; k < ns; ++k, ++g) {
+			const cs_seed_t s = sd[ord[k]];
+			bool around = false;
+			for (uint64_t base = g0; base < g && !around; base += 64) {
+				const uint64_t i = base + (uint64_t)lane;
+				bool hit = false;
+				if (i < g && !pf[i]) { const cs_alnreg_t a = A.regs[i]; const PReg p = {a.rb, a.re, a.qb, a.qe, a.seedlen0, a.w}; hit = purge_around(s, p, l_query, [&](int x) { return affordable_gap(o, x); }); }
+				around = __ballot(hit) != 0;
+			}
+			if (!around) continue;
+			bool rival = false;
+			for (int base = 0; base < k && !rival; base += 64) {
+				const int v = base + lane;
+				const bool hit = v < k && !pf[s0 + (uint64_t)v] && purge_rival(s, sd[ord[v]]);
+				rival = __ballot(hit) != 0;
+			}
+			if (rival) continue;
+			if (lane == 0) { pf[g] = 1; A.regs[g].qb = -1; A.regs[g].qe = -1; ++my; }
+			__threadfence();
+		}
+	}
+}
+// the reads with more than 64 regions (reads inside repeats: hundreds to thousands of regions, and the walk is quadratic): a workgroup of four
+// waves per read, the read's regions and seeds staged in the LDS -- a step of the walk costs LDS round trips instead of HBM ones, 256 earlier
+// regions are looked at per round, the affordable gap (two divisions in double precision) comes from a table over the read's length, both
+// tests of a step are answered with ONE barrier (every wave casts its two votes, double-buffered), and the reads are handed out by a ticket
+// counter (a few reads of 2,000 regions are most of the work).  All 160 KB of a CU's LDS: one read per CU at a time.
+constexpr int PURGE_CAP = 3000, PURGE_GAPS = 1024;
+__global__ __launch_bounds__(256) void purge_big_kernel(const Args A, uint8_t *pflag)
+{
+	__shared__ PReg l_reg[PURGE_CAP];
+	__shared__ cs_seed_t l_seed[PURGE_CAP];
+	__shared__ int32_t l_first[PURGE_CAP];
+	__shared__ uint8_t l_alive[PURGE_CAP];
+	__shared__ int32_t l_gap[PURGE_GAPS];
+	__shared__ unsigned long long l_ticket;
+	__shared__ uint32_t l_vote[2][4];
+	const cs_aln_params_t &o = A.o;
+	const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint64_t n_big = A.ctr[6];
+	unsigned long long my = 0;
+	for (int x = tid; x < PURGE_GAPS; x += 256) l_gap[x] = affordable_gap(o, x);
+	for (;;) {
+		__syncthreads();                                            // (the previous read's last LDS reads are done)
+		if (tid == 0) l_ticket = atomicAdd(A.ctr + 7, 1ull);
+		__syncthreads();
+		const uint64_t e = l_ticket;
+		if (e >= n_big) break;
+		const int64_t r = (int64_t)A.big_reads[e];
+		const uint64_t g0 = A.cseed_off[A.chain_off[r]], g1 = A.cseed_off[A.chain_off[r + 1]];
+		if (g1 - g0 > (uint64_t)A.purge_cap) { if (tid < 64) purge_read_global(A, r, pflag, lane, my); continue; }
+		const int G = (int)(g1 - g0), l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
+		auto gap_of = [&](int x) { return (unsigned)x < (unsigned)PURGE_GAPS ? l_gap[x] : affordable_gap(o, x); };
+		for (int i = tid; i < G; i += 256) { PReg p; cs_seed_t s; int first; purge_load(A, g0, g0 + (uint64_t)i, p, s, first); l_reg[i] = p; l_seed[i] = s; l_first[i] = first; l_alive[i] = 1; }
+		__syncthreads();
+		for (int g = 1; g < G; ++g) {
+			const cs_seed_t sg = l_seed[g];
+			bool around = false, rival = false;
+			for (int i = tid; i < g && !around; i += 256) around = l_alive[i] && purge_around(sg, l_reg[i], l_query, gap_of);
+			for (int v = l_first[g] + tid; v < g && !rival; v += 256) rival = l_alive[v] && purge_rival(sg, l_seed[v]);
+			const uint32_t vote = (__ballot(around) ? 1u : 0u) | (__ballot(rival) ? 2u : 0u);
+			if (lane == 0) l_vote[g & 1][wv] = vote;
+			__syncthreads();
+			const uint32_t all = l_vote[g & 1][0] | l_vote[g & 1][1] | l_vote[g & 1][2] | l_vote[g & 1][3];
+			if (all != 1u) continue;                                // not inside an earlier region, or defended by a rival
+			if (lane == 0) l_alive[g] = 0;                          // (every wave for itself: its own later reads follow its own write)
+			if (tid == 0) ++my;
+		}
+		for (int i = tid; i < G; i += 256) if (!l_alive[i]) { A.regs[g0 + (uint64_t)i].qb = -1; A.regs[g0 + (uint64_t)i].qe = -1; }
 	}
 	if (lane == 0 && my) atomicAdd(A.ctr + 4, my);
 }
@@ -298,7 +445,7 @@ int ensure(Buf &b, size_t bytes)
 	return CS_OK;
 }
 enum { B_CHAIN_OFF, B_CSEED_OFF, B_READ_OFF, B_CHAINS, B_CSEEDS, B_SCORE, B_BASES, B_PAC, B_CTG_OFF, B_CTG_LEN, B_CHAIN_READ, B_W0, B_WLEN2, B_TB0, B_QBUF, B_TBUF, B_ORD, B_REGS,
-       B_REG_CI, B_LP, B_RP, B_RETRY, B_RES, B_CTR, B_SCAN, B_PFLAG, B_COUNT };
+       B_REG_CI, B_LP, B_RP, B_RETRY, B_RES, B_CTR, B_SCAN, B_PFLAG, B_BIG, B_BIG_READS, B_COUNT };
 } // namespace
 
 struct cs_aligner_gpu { int device = 0, n_cu = 256; hipStream_t s = nullptr; Buf b[B_COUNT]; bool pac_up = false; unsigned long long *h_ctr = nullptr; };
@@ -335,10 +482,10 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	auto lap = [](const char *) {};
 #endif
 	const int64_t n = chains->n_reads, nc = (int64_t)chains->n_chains, ns = (int64_t)chains->n_seeds;
-	reg_off.assign((size_t)n + 1, 0); regs.clear();
+	reg_off.assign((size_t)n + 1, 0);                              // (regs keeps its size from call to call: growing a vector by 200 MB of zeroes took 6 ms per million reads)
 	for (int64_t r = 0; r < n; ++r) reg_off[(size_t)r + 1] = chains->cseed_off[chains->chain_off[r + 1]];
 	st.reads += (uint64_t)n;
-	if (ns == 0) return CS_OK;
+	if (ns == 0) { regs.clear(); return CS_OK; }
 	if (ns >= 0x7fffffffll || nc >= 0xffffffffll) return cs_fail_(CS_ERANGE, "cs_extend_chains: more than 2^31 regions in one call");
 	const uint64_t n_bases = read_offsets[n];
 	auto up = [&](int which, const void *src, size_t bytes) -> int {
@@ -362,7 +509,8 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 		G.pac_up = true;
 	}
 	lap("uploads");
-	for (int which : {B_CHAIN_READ}) if (int rc = ensure(G.b[which], (size_t)nc * 4 + 64)) return rc;
+	for (int which : {B_CHAIN_READ, B_BIG}) if (int rc = ensure(G.b[which], (size_t)nc * 4 + 64)) return rc;
+	if (int rc = ensure(G.b[B_BIG_READS], (size_t)n * 4 + 64)) return rc;
 	for (int which : {B_W0, B_WLEN2, B_TB0}) if (int rc = ensure(G.b[which], ((size_t)nc + 1) * 8 + 64)) return rc;
 	if (int rc = ensure(G.b[B_QBUF], (size_t)n_bases * 2 + 64)) return rc;
 	for (int which : {B_ORD, B_REG_CI}) if (int rc = ensure(G.b[which], (size_t)ns * 4 + 64)) return rc;
@@ -381,6 +529,9 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	A.chain_read = (uint32_t *)G.b[B_CHAIN_READ].p; A.w0 = (int64_t *)G.b[B_W0].p; A.wlen2 = (uint64_t *)G.b[B_WLEN2].p; A.tb0 = (uint64_t *)G.b[B_TB0].p;
 	A.qbuf = (uint8_t *)G.b[B_QBUF].p; A.tbuf = nullptr; A.ord = (uint32_t *)G.b[B_ORD].p; A.regs = (cs_alnreg_t *)G.b[B_REGS].p; A.reg_ci = (uint32_t *)G.b[B_REG_CI].p;
 	A.lp = (cs_ext_pair_t *)G.b[B_LP].p; A.rp = (cs_ext_pair_t *)G.b[B_RP].p; A.ctr = (unsigned long long *)G.b[B_CTR].p;
+	A.big = (uint32_t *)G.b[B_BIG].p; A.big_reads = (uint32_t *)G.b[B_BIG_READS].p;
+	A.small_chain = (o.flags & CS_ALN_NO_LIGHT_PATHS) ? 0 : csa::SMALL_CHAIN; A.light_max = (o.flags & CS_ALN_NO_LIGHT_PATHS) ? 1 : 64;
+	A.purge_cap = (o.flags & CS_ALN_PURGE_FROM_HBM) ? 0 : csa::PURGE_CAP;
 	auto grid = [&](int64_t items, int per_block = 256) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + per_block - 1) / per_block, (int64_t)G.n_cu * 16))); };
 
 	lap("buffers");
@@ -404,7 +555,9 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	if (int rc = ensure(G.b[B_TBUF], (size_t)t_bytes + 64)) return rc;
 	A.tbuf = (uint8_t *)G.b[B_TBUF].p;
 	hipLaunchKernelGGL(csa::fill_kernel, grid(nc * 64), dim3(256), 0, s, A);
+	lap("fill");
 	hipLaunchKernelGGL(csa::region_kernel, grid(nc), dim3(256), 0, s, A);
+	hipLaunchKernelGGL(csa::region_big_kernel, dim3((unsigned)G.n_cu * 8), dim3(256), 0, s, A);
 	HIP_TRYA(hipGetLastError());
 	HIP_TRYA(hipMemcpyAsync(G.h_ctr, A.ctr, 2 * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRYA(hipStreamSynchronize(s));
@@ -439,7 +592,9 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	lap("seedcov");
 	if (int rc = ensure(G.b[B_PFLAG], (size_t)ns + 64)) return rc;
 	HIP_TRYA(hipMemsetAsync(G.b[B_PFLAG].p, 0, (size_t)ns, s));
-	hipLaunchKernelGGL(csa::purge_kernel, grid(n * 64), dim3(256), 0, s, A, (uint8_t *)G.b[B_PFLAG].p);
+	hipLaunchKernelGGL(csa::purge_kernel, grid(n * 64), dim3(256), 0, s, A);
+	lap("purge, light reads");
+	hipLaunchKernelGGL(csa::purge_big_kernel, dim3((unsigned)G.n_cu), dim3(256), 0, s, A, (uint8_t *)G.b[B_PFLAG].p);
 	HIP_TRYA(hipGetLastError());
 	lap("purge");
 	regs.resize((size_t)ns);

@@ -250,30 +250,23 @@ extern "C" int cs_chain_batch(cs_chainer_t *c, const cs_chain_params_t *par, con
 	const int64_t n = seeds->n_reads;
 	int T = std::max(1, std::min(n_threads, 256));
 	if (n < 1024) T = 1;
-	std::vector<ReadOut> part((size_t)T);
-	std::vector<std::thread> th;
-	for (int t = 0; t < T; ++t) {
-		const int64_t r0 = n * t / T, r1 = n * (t + 1) / T;
-		if (T == 1) chain_range(c->ref, *par, *seeds, read_offsets, r0, r1, part[0]);
-		else th.emplace_back(chain_range, std::cref(c->ref), std::cref(*par), std::cref(*seeds), read_offsets, r0, r1, std::ref(part[(size_t)t]));
-	}
-	for (auto &t : th) t.join();
-	// join: every thread's share goes to where the prefix sums over the threads say, copied by the threads side by side
-	std::vector<size_t> cb((size_t)T + 1, 0), sb((size_t)T + 1, 0);
-	for (int t = 0; t < T; ++t) { cb[(size_t)t + 1] = cb[(size_t)t] + part[(size_t)t].chains.size(); sb[(size_t)t + 1] = sb[(size_t)t] + part[(size_t)t].seeds.size(); }
-	c->chains.resize(cb[(size_t)T]); c->cseeds.resize(sb[(size_t)T]); c->chain_off.resize((size_t)n + 1); c->cseed_off.resize(cb[(size_t)T] + 1);
+	// chunks of reads, handed out by a counter (cs_for_chunks_); every chunk's share goes to where the prefix sums over the chunks say
+	const int64_t CH = cs_chunk_reads_(n, T), K = (n + CH - 1) / CH;
+	std::vector<ReadOut> part((size_t)K);
+	cs_for_chunks_(T, K, [&](int64_t k) { chain_range(c->ref, *par, *seeds, read_offsets, k * CH, std::min(n, (k + 1) * CH), part[(size_t)k]); });
+	std::vector<size_t> cb((size_t)K + 1, 0), sb((size_t)K + 1, 0);
+	for (int64_t k = 0; k < K; ++k) { cb[(size_t)k + 1] = cb[(size_t)k] + part[(size_t)k].chains.size(); sb[(size_t)k + 1] = sb[(size_t)k] + part[(size_t)k].seeds.size(); }
+	c->chains.resize(cb[(size_t)K]); c->cseeds.resize(sb[(size_t)K]); c->chain_off.resize((size_t)n + 1); c->cseed_off.resize(cb[(size_t)K] + 1);
 	c->chain_off[0] = 0; c->cseed_off[0] = 0;
-	auto join = [&](int t) {
-		const ReadOut &p = part[(size_t)t];
-		uint64_t co = cb[(size_t)t], so = sb[(size_t)t];
-		int64_t r = n * t / T;
-		for (uint32_t k : p.per_read) { co += k; c->chain_off[(size_t)++r] = co; }
-		for (size_t i = 0; i < p.chains.size(); ++i) { so += (uint64_t)p.chains[i].n_seeds; c->cseed_off[cb[(size_t)t] + i + 1] = so; }
-		if (!p.chains.empty()) memcpy(c->chains.data() + cb[(size_t)t], p.chains.data(), p.chains.size() * sizeof(cs_chain_t));
-		if (!p.seeds.empty()) memcpy(c->cseeds.data() + sb[(size_t)t], p.seeds.data(), p.seeds.size() * sizeof(cs_seed_t));
-	};
-	if (T == 1) join(0);
-	else { std::vector<std::thread> tj; for (int t = 0; t < T; ++t) tj.emplace_back(join, t); for (auto &t : tj) t.join(); }
+	cs_for_chunks_(T, K, [&](int64_t k) {
+		const ReadOut &p = part[(size_t)k];
+		uint64_t co = cb[(size_t)k], so = sb[(size_t)k];
+		int64_t r = k * CH;
+		for (uint32_t q : p.per_read) { co += q; c->chain_off[(size_t)++r] = co; }
+		for (size_t i = 0; i < p.chains.size(); ++i) { so += (uint64_t)p.chains[i].n_seeds; c->cseed_off[cb[(size_t)k] + i + 1] = so; }
+		if (!p.chains.empty()) memcpy(c->chains.data() + cb[(size_t)k], p.chains.data(), p.chains.size() * sizeof(cs_chain_t));
+		if (!p.seeds.empty()) memcpy(c->cseeds.data() + sb[(size_t)k], p.seeds.data(), p.seeds.size() * sizeof(cs_seed_t));
+	});
 	out->n_reads = n; out->n_chains = c->chains.size(); out->n_seeds = c->cseeds.size();
 	out->chain_off = c->chain_off.data(); out->chains = c->chains.data(); out->cseed_off = c->cseed_off.data(); out->cseeds = c->cseeds.data();
 	return CS_OK;

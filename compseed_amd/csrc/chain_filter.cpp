@@ -211,9 +211,12 @@ extern "C" int cs_chain_filter(cs_chainer_t *c, const cs_flt_params_t *par, cons
 	for (uint64_t k = 0; k < in->n_chains; ++k) if (in->cseed_off[k + 1] <= in->cseed_off[k]) return cs_fail_(CS_EINVAL, "cs_chain_filter: a chain without seeds");
 	// the seed test reads the reference: needed only when some read is long enough for it (and then its bases are, too)
 	bool need_pac = false;
+	double l_seen = -1.;                                            // (a batch has few distinct lengths: one logarithm each, not one per read)
 	for (int64_t r = 0; r < n && !need_pac; ++r) {
 		const double l = (double)(read_offsets[r + 1] - read_offsets[r]);
-		if (l > 0 && in->chain_off[r + 1] > in->chain_off[r]) { const double min_l = par->min_chain_weight ? 1.1f * (float)par->min_chain_weight : 5.5f * std::log(l); need_pac = !(min_l > 0.05f * (float)l); }
+		if (l == l_seen) continue;
+		if (l > 0 && in->chain_off[r + 1] > in->chain_off[r]) {
+			l_seen = l; const double min_l = par->min_chain_weight ? 1.1f * (float)par->min_chain_weight : 5.5f * std::log(l); need_pac = !(min_l > 0.05f * (float)l); }
 	}
 	if (need_pac) {
 		if (!bases) return cs_fail_(CS_EINVAL, "cs_chain_filter: the reads are needed for the seed test of long reads");
@@ -221,30 +224,23 @@ extern "C" int cs_chain_filter(cs_chainer_t *c, const cs_flt_params_t *par, cons
 	}
 	int T = std::max(1, std::min(n_threads, 256));
 	if (n < 1024) T = 1;
-	std::vector<ReadOut> part((size_t)T);
-	std::vector<std::thread> th;
-	for (int t = 0; t < T; ++t) {
-		const int64_t r0 = n * t / T, r1 = n * (t + 1) / T;
-		if (T == 1) filter_range(*c, *par, *in, bases, read_offsets, r0, r1, part[0]);
-		else th.emplace_back(filter_range, std::cref(*c), std::cref(*par), std::cref(*in), bases, read_offsets, r0, r1, std::ref(part[(size_t)t]));
-	}
-	for (auto &t : th) t.join();
-	// join: every thread's share goes to where the prefix sums over the threads say, copied by the threads side by side
-	std::vector<size_t> cb((size_t)T + 1, 0), sb((size_t)T + 1, 0);
-	for (int t = 0; t < T; ++t) { cb[(size_t)t + 1] = cb[(size_t)t] + part[(size_t)t].chains.size(); sb[(size_t)t + 1] = sb[(size_t)t] + part[(size_t)t].seeds.size(); }
-	c->f_chains.resize(cb[(size_t)T]); c->f_cseeds.resize(sb[(size_t)T]); c->f_score.resize(sb[(size_t)T]); c->f_chain_off.resize((size_t)n + 1); c->f_cseed_off.resize(cb[(size_t)T] + 1);
+	// chunks of reads, handed out by a counter (cs_for_chunks_); every chunk's share goes to where the prefix sums over the chunks say
+	const int64_t CH = cs_chunk_reads_(n, T), K = (n + CH - 1) / CH;
+	std::vector<ReadOut> part((size_t)K);
+	cs_for_chunks_(T, K, [&](int64_t k) { filter_range(*c, *par, *in, bases, read_offsets, k * CH, std::min(n, (k + 1) * CH), part[(size_t)k]); });
+	std::vector<size_t> cb((size_t)K + 1, 0), sb((size_t)K + 1, 0);
+	for (int64_t k = 0; k < K; ++k) { cb[(size_t)k + 1] = cb[(size_t)k] + part[(size_t)k].chains.size(); sb[(size_t)k + 1] = sb[(size_t)k] + part[(size_t)k].seeds.size(); }
+	c->f_chains.resize(cb[(size_t)K]); c->f_cseeds.resize(sb[(size_t)K]); c->f_score.resize(sb[(size_t)K]); c->f_chain_off.resize((size_t)n + 1); c->f_cseed_off.resize(cb[(size_t)K] + 1);
 	c->f_chain_off[0] = 0; c->f_cseed_off[0] = 0;
-	auto join = [&](int t) {
-		const ReadOut &p = part[(size_t)t];
-		uint64_t co = cb[(size_t)t], so = sb[(size_t)t];
-		int64_t r = n * t / T;
-		for (uint32_t k : p.per_read) { co += k; c->f_chain_off[(size_t)++r] = co; }
-		for (size_t i = 0; i < p.chains.size(); ++i) { so += (uint64_t)p.chains[i].n_seeds; c->f_cseed_off[cb[(size_t)t] + i + 1] = so; }
-		if (!p.chains.empty()) memcpy(c->f_chains.data() + cb[(size_t)t], p.chains.data(), p.chains.size() * sizeof(cs_chain_t));
-		if (!p.seeds.empty()) { memcpy(c->f_cseeds.data() + sb[(size_t)t], p.seeds.data(), p.seeds.size() * sizeof(cs_seed_t)); memcpy(c->f_score.data() + sb[(size_t)t], p.score.data(), p.score.size() * sizeof(int32_t)); }
-	};
-	if (T == 1) join(0);
-	else { std::vector<std::thread> tj; for (int t = 0; t < T; ++t) tj.emplace_back(join, t); for (auto &t : tj) t.join(); }
+	cs_for_chunks_(T, K, [&](int64_t k) {
+		const ReadOut &p = part[(size_t)k];
+		uint64_t co = cb[(size_t)k], so = sb[(size_t)k];
+		int64_t r = k * CH;
+		for (uint32_t q : p.per_read) { co += q; c->f_chain_off[(size_t)++r] = co; }
+		for (size_t i = 0; i < p.chains.size(); ++i) { so += (uint64_t)p.chains[i].n_seeds; c->f_cseed_off[cb[(size_t)k] + i + 1] = so; }
+		if (!p.chains.empty()) memcpy(c->f_chains.data() + cb[(size_t)k], p.chains.data(), p.chains.size() * sizeof(cs_chain_t));
+		if (!p.seeds.empty()) { memcpy(c->f_cseeds.data() + sb[(size_t)k], p.seeds.data(), p.seeds.size() * sizeof(cs_seed_t)); memcpy(c->f_score.data() + sb[(size_t)k], p.score.data(), p.score.size() * sizeof(int32_t)); }
+	});
 	out->n_reads = n; out->n_chains = c->f_chains.size(); out->n_seeds = c->f_cseeds.size();
 	out->chain_off = c->f_chain_off.data(); out->chains = c->f_chains.data(); out->cseed_off = c->f_cseed_off.data(); out->cseeds = c->f_cseeds.data();
 	if (cseed_score) *cseed_score = c->f_score.data();

@@ -185,24 +185,18 @@ int cs_dedup_regions_(const cs_aligner_core &A, const cs_dedup_params_t *par, co
 	const int64_t n = regs->n_reads;
 	int T = std::max(1, std::min(A.par->threads, 256));
 	if (n < 1024) T = 1;
-	std::vector<std::vector<Reg>> part((size_t)T); std::vector<std::vector<uint32_t>> cnt((size_t)T);
-	std::vector<std::thread> th;
-	for (int t = 0; t < T; ++t) {
-		const int64_t r0 = n * t / T, r1 = n * (t + 1) / T;
-		if (T == 1) dedup_range(A, *par, *regs, bases, read_offsets, r0, r1, part[0], cnt[0]);
-		else th.emplace_back(dedup_range, std::cref(A), std::cref(*par), std::cref(*regs), bases, read_offsets, r0, r1, std::ref(part[(size_t)t]), std::ref(cnt[(size_t)t]));
-	}
-	for (auto &t : th) t.join();
-	std::vector<size_t> rb((size_t)T + 1, 0);
-	for (int t = 0; t < T; ++t) rb[(size_t)t + 1] = rb[(size_t)t] + part[(size_t)t].size();
-	out_off.resize((size_t)n + 1); out_off[0] = 0; out_regs.resize(rb[(size_t)T]); out_ncomp.resize(rb[(size_t)T]);
-	auto join = [&](int t) { // every thread's share to where the prefix sums say
-		uint64_t o = rb[(size_t)t]; int64_t r = n * t / T;
-		for (uint32_t k : cnt[(size_t)t]) { o += k; out_off[(size_t)++r] = o; }
-		size_t i = rb[(size_t)t];
-		for (const Reg &g : part[(size_t)t]) { out_regs[i] = g.r; out_ncomp[i] = g.n_comp; ++i; }
-	};
-	if (T == 1) join(0);
-	else { std::vector<std::thread> tj; for (int t = 0; t < T; ++t) tj.emplace_back(join, t); for (auto &t : tj) t.join(); }
+	// chunks of reads, handed out by a counter (cs_for_chunks_: a read with 2,000 regions is two million pair tests)
+	const int64_t CH = cs_chunk_reads_(n, T), K = (n + CH - 1) / CH;
+	std::vector<std::vector<Reg>> part((size_t)K); std::vector<std::vector<uint32_t>> cnt((size_t)K);
+	cs_for_chunks_(T, K, [&](int64_t k) { dedup_range(A, *par, *regs, bases, read_offsets, k * CH, std::min(n, (k + 1) * CH), part[(size_t)k], cnt[(size_t)k]); });
+	std::vector<size_t> rb((size_t)K + 1, 0);
+	for (int64_t k = 0; k < K; ++k) rb[(size_t)k + 1] = rb[(size_t)k] + part[(size_t)k].size();
+	out_off.resize((size_t)n + 1); out_off[0] = 0; out_regs.resize(rb[(size_t)K]); out_ncomp.resize(rb[(size_t)K]);
+	cs_for_chunks_(T, K, [&](int64_t k) { // every chunk's share to where the prefix sums say
+		uint64_t o = rb[(size_t)k]; int64_t r = k * CH;
+		for (uint32_t q : cnt[(size_t)k]) { o += q; out_off[(size_t)++r] = o; }
+		size_t i = rb[(size_t)k];
+		for (const Reg &g : part[(size_t)k]) { out_regs[i] = g.r; out_ncomp[i] = g.n_comp; ++i; }
+	});
 	return CS_OK;
 }

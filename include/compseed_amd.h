@@ -370,7 +370,11 @@ int  cs_extend_batch_resident(cs_extender_t *x, int64_t n_pairs, const cs_ext_pa
  *      batch's reads (ASCII or codes; a '-' is code 5 as in nst_nt4_table).  The aligner loads <prefix>.ann / .alt / .pac.  The result arrays
  *      belong to the aligner and stay valid until its next call.  pen_clip5 must equal pen_clip3 for now. */
 typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop; /* mem_opt_t: -A -B -O -E -L -w -d */
-                 int32_t threads;   /* [16] host threads that build windows / pairs and run the passes around the kernel */ } cs_aln_params_t;
+                 int32_t threads;   /* [16] host threads of the passes around the kernels (cs_dedup_regions) */
+                 uint32_t flags;    /* [0] CS_ALN_* below: A/B switches of cs_extend_chains, every combination gives the same regions */ } cs_aln_params_t;
+#define CS_ALN_NO_LIGHT_PATHS 1u   /* every chain through the wave-per-chain region kernel, every read through the LDS purge kernel (default: chains of up to 8 seeds a lane
+                                    * each, reads of up to 64 regions a wave each in registers) */
+#define CS_ALN_PURGE_FROM_HBM 2u   /* reads of more than 64 regions purged straight from HBM: the fallback for a read whose regions do not fit the LDS (3,000) */
 typedef struct { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0; float frac_rep; int32_t chain; } cs_alnreg_t;
 typedef struct { int64_t n_reads; uint64_t n_regs; const uint64_t *reg_off; const cs_alnreg_t *regs; } cs_aln_result_t;
 typedef struct { uint64_t reads, regions, pairs, retries, purged, launches;   /* pairs = extensions run incl. retries */

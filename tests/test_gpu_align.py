@@ -29,8 +29,12 @@ def _load(name):
     return z, bases, off
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", ["main100", "sorted150", "ragged", "repeat100", "indel150_400", "long90", "gap3k"])
-def test_alignment_regions_are_the_references(name):
+def test_alignment_regions_are_the_references(name, flags):
+    """flags: cs_aln_params_t.flags -- 0 = chains of up to 8 seeds a lane each / reads of up to 64 regions in registers, the rest a wave per chain / the
+    LDS purge; 1 = everything through the wave-per-chain and LDS kernels; 2 = reads of more than 64 regions purged from HBM (the fallback beyond the LDS's
+    3,000 regions); 3 = both.  Every path must give the reference's regions."""
     import compseed_amd as ca
     z, bases, off = _load(name)
     n_chains = z["chain_pos"].size
@@ -39,9 +43,11 @@ def test_alignment_regions_are_the_references(name):
     cseed_off = np.zeros(n_chains + 1, dtype=np.uint64); np.cumsum(z["chain_n"].astype(np.uint64), out=cseed_off[1:])
     cseeds = np.zeros(z["cseed_rbeg"].size, dtype=ca.SEED_DT)
     cseeds["rbeg"], cseeds["qbeg"], cseeds["len"] = z["cseed_rbeg"], z["cseed_qbeg"], z["cseed_len"]
-    al = ca.Aligner(_data.PREFIX, 0)
+    al = ca.Aligner(_data.PREFIX, 0, ca.AlnParams(flags=flags))
     got = al.extend_chains(z["chain_off"], chains, cseed_off, cseeds, bases, off, cseed_score=z["cseed_score"])
     st = al.stats()
+    per_read = np.diff(got["reg_off"].astype(np.int64))
+    if name == "repeat100": assert per_read.max() > 64 and z["chain_n"].max() > 8   # (the heavy paths are exercised at flags 0, too)
     al.close()
     assert np.array_equal(got["reg_off"], z["reg_off"])
     g = got["regs"]

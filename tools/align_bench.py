@@ -59,7 +59,7 @@ def run(n=200000, synth_mbp=0.0):
     ix = ca.Index.load(PREFIX); eng = ca.Engine(ix, 0); ch = ca.Chainer(PREFIX); al = ca.Aligner(PREFIX, 0)
     out = {"reads": n, "reference": ("synthetic %g Mbp" % synth_mbp) if synth_mbp > 0 else "tests/golden/g1 (220 kbp, tandem arrays)"}
     for rep in range(2):   # the second round is the measured one (buffers sized)
-        t0 = time.perf_counter(); res = eng.seed_batch(bases, off, ca.Params()); t1 = time.perf_counter()
+        t0 = time.perf_counter(); res = eng.seed_batch(bases, off, ca.Params(), copy=False); t1 = time.perf_counter()
         c = ch.chain(res.mem_off, res.mems, res.seed_off, res.seeds, off, ca.ChainParams(), threads=16, copy=False); t2 = time.perf_counter()
         f = ch.filter(c["chain_off"], c["chains"], c["cseed_off"], c["cseeds"], bases, off, threads=16, copy=False); t3 = time.perf_counter()
         st0 = al.stats()
@@ -70,6 +70,10 @@ def run(n=200000, synth_mbp=0.0):
         out[name] = {"ms": 1e3 * (b - a), "reads_per_s": n / (b - a)}
     out["counts"] = {"seeds": int(res.n_seeds), "chains": int(c["chains"].size), "chains_after_filter": int(f["chains"].size), "regions": int(g["regs"].size),
                      "regions_after_dedup": int(d["regs"].size), "extensions": int(st1["pairs"] - st0["pairs"]), "ext_launches": int(st1["launches"] - st0["launches"])}
+    per_read = np.diff(np.asarray(g["reg_off"]).astype(np.int64))
+    out["regions_per_read"] = {"mean": float(per_read.mean()), "p50": float(np.percentile(per_read, 50)), "p99": float(np.percentile(per_read, 99)), "p99.9": float(np.percentile(per_read, 99.9)),
+                               "max": int(per_read.max()), "reads_over_64": int((per_read > 64).sum()), "reads_over_1024": int((per_read > 1024).sum()),
+                               "sum_sq_over_64": float(((per_read.astype(np.float64) ** 2) / 64).sum())}
     kms = st1["ext_kernel_ms"] - st0["ext_kernel_ms"]
     out["extension_kernels"] = {"ms": kms, "pairs_per_s": (st1["pairs"] - st0["pairs"]) / (kms * 1e-3) if kms > 0 else None, "dp_cells_per_pair": (st1["ext_cells"] - st0["ext_cells"]) / max(1, st1["pairs"] - st0["pairs"]),
                                 "note": "the extension kernels alone (HIP events) on this run's own pairs: extensions of real chains die at different rows, unlike the uniform pairs of tools/extend_bench.py"}
