@@ -562,7 +562,7 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	HIP_TRYA(hipMemcpyAsync(G.h_ctr, A.ctr, 2 * 8, hipMemcpyDeviceToHost, s));
 	HIP_TRYA(hipStreamSynchronize(s));
 	const uint64_t n_left = G.h_ctr[0], n_right = G.h_ctr[1];
-	lap("fill, regions");
+	lap("regions");
 
 	// ---- the dynamic programming (extend.hip), each side: band w, then 2w for the pairs whose path came close to the band's edge
 	auto run_side = [&](cs_ext_pair_t *pairs, uint64_t cnt, bool is_left, int pen_clip) -> int {
