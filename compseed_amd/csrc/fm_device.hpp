@@ -59,16 +59,24 @@ enum : int { KID_FWD0 = 0, KID_FWD, KID_BWD_WIN, KID_BWD_WIN0, KID_BWD_WIDE, KID
 template <bool ON> struct WaveCtrT;
 template <> struct WaveCtrT<true> {
 	uint32_t v[N_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                               // this LANE's events
-#ifdef CS_X2_HIST // experiment build (make variant DEFS=-DCS_X2_HIST): the ten event slots hold a histogram of the interval sizes extend1 is asked for
+#ifdef CS_STEP_HIST // experiment build (make variant DEFS=-DCS_STEP_HIST): slots 0..7 = iterations of bwd_win_kernel's wave loop by the number of lanes that extend in it (0, 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64), slot 8 = the extensions
+	__device__ __forceinline__ void add(int, uint32_t) {}
+	__device__ __forceinline__ void addn(int, uint32_t) {}
+	__device__ __forceinline__ void rec(bool) {}
+	__device__ __forceinline__ void hist(uint32_t) {}
+	__device__ __forceinline__ void steps(uint32_t n) { if ((threadIdx.x & 63u) == 0) { v[n == 0 ? 0 : n == 1 ? 1 : n == 2 ? 2 : n <= 4 ? 3 : n <= 8 ? 4 : n <= 16 ? 5 : n <= 32 ? 6 : 7] += 1u; v[8] += n; } }
+#elif defined(CS_X2_HIST) // experiment build (make variant DEFS=-DCS_X2_HIST): the ten event slots hold a histogram of the interval sizes extend1 is asked for
 	__device__ __forceinline__ void add(int, uint32_t) {}
 	__device__ __forceinline__ void addn(int, uint32_t) {}
 	__device__ __forceinline__ void rec(bool) {}
 	__device__ __forceinline__ void hist(uint32_t x2) { v[x2 <= 1 ? 0 : x2 <= 2 ? 1 : x2 <= 4 ? 2 : x2 <= 8 ? 3 : x2 <= 16 ? 4 : x2 <= 64 ? 5 : x2 <= 256 ? 6 : x2 <= 4096 ? 7 : x2 <= 65536 ? 8 : 9] += 1u; }
+	__device__ __forceinline__ void steps(uint32_t) {}
 #else
 	__device__ __forceinline__ void add(int ev, uint32_t n) { v[ev] += n; }
 	__device__ __forceinline__ void addn(int ev, uint32_t n) { v[ev] += n; }
 	__device__ __forceinline__ void rec(bool two) { v[EV_REC] += two ? 2u : 1u; }
 	__device__ __forceinline__ void hist(uint32_t) {}
+	__device__ __forceinline__ void steps(uint32_t) {}
 #endif
 	__device__ __forceinline__ void flush(unsigned long long *evc, int kid) const                    // every lane of the wave must call it
 	{
@@ -84,6 +92,7 @@ template <> struct WaveCtrT<false> {
 	__device__ __forceinline__ void addn(int, uint32_t) {}
 	__device__ __forceinline__ void rec(bool) {}
 	__device__ __forceinline__ void hist(uint32_t) {}
+	__device__ __forceinline__ void steps(uint32_t) {}
 	__device__ __forceinline__ void flush(unsigned long long *, int) const {}
 };
 using WaveCtr = WaveCtrT<true>;

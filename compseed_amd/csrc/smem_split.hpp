@@ -953,6 +953,9 @@ __device__ __forceinline__ void bwd_win_run(const SplitArgs &A, const BTask *bq,
 		}
 		if (exhausted && avail_m == 0 && __ballot(active) == 0) break; // wave-uniform exit
 		uint64_t push0 = FTASK_NONE, push1 = FTASK_NONE, aux0 = AUX_NONE;
+#ifdef CS_STEP_HIST
+		W.steps((uint32_t)__popcll(__ballot(active && walking && s == clk)));
+#endif
 		if (active) {
 			// One clock per group: position clk is the read base every walking lane prepends in this iteration.  A lane joins
 			// when the clock reaches the base in front of its match (the window lanes start staggered, the LEPs at the pivot),
