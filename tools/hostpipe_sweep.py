@@ -23,11 +23,13 @@ for spec in sys.argv[1:] or [""]:
     for _ in range(depth):
         eng.submit(pin, ho)
     tt = []
-    for i in range(24):
+    NB = 64                              # batches in the stream; timed: the 40 in the middle
+    for i in range(NB):
         eng.collect_packed(); tt.append(time.perf_counter())
-        if i + depth < 24:
+        if i + depth < NB:
             eng.submit(pin, ho)
-    per = (tt[20] - tt[8]) / 12 * 1e3
-    print("%-50s blocking packed: min %.1f median %.1f ms (%.1f M reads/s) | stream: %.1f ms per batch (%.1f M reads/s)" %
-          (spec or "defaults", min(ts), sorted(ts)[2], n / sorted(ts)[2] / 1e3, per, n / per / 1e3), flush=True)
+    per = (tt[52] - tt[12]) / 40 * 1e3
+    gaps = np.diff(np.array(tt[12:53])) * 1e3
+    print("%-50s blocking packed: min %.1f median %.1f ms (%.1f M reads/s) | stream: %.1f ms per batch (%.1f M reads/s; between collects: median %.1f, 10th-90th percentile %.1f-%.1f ms)" %
+          (spec or "defaults", min(ts), sorted(ts)[2], n / sorted(ts)[2] / 1e3, per, n / per / 1e3, np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90)), flush=True)
     eng.close()
