@@ -19,6 +19,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -81,12 +83,74 @@ int striped_sw_score(int qlen, const uint8_t *q, int tlen, const uint8_t *t, con
 
 struct ReadOut { std::vector<cs_chain_t> chains; std::vector<cs_seed_t> seeds; std::vector<int32_t> score; std::vector<uint32_t> per_read; };
 
+// ---- the overlap scan of mem_chain_flt (comp_seed.cpp:311-336).  Chains in descending weight; chain i is compared with the chains kept so far,
+// in the order they were kept: a kept chain j that overlaps i significantly on the read gets i as its `first` shadow (if it has none), and if i is
+// much lighter than j the scan stops there and i is not kept; a chain that reaches the end of the list is kept (2: overlapping, 3: on its own).
+// The loop as the reference writes it -- quadratic where nothing is "much lighter", e.g. the thousands of equal chains of a read inside a
+// tandem array: 6.6 G steps for 400,000 reads of the golden reference, all of cs_chain_filter's time there.
+inline bool sig_overlap(const cs_flt_params_t &o, int bj, int ej, bool aj, int bi, int ei, bool ai)
+{
+	const int b_max = std::max(bj, bi), e_min = std::min(ej, ei);
+	if (!(e_min > b_max && (!aj || ai))) return false;   // no overlap on the read (not counted when the kept chain is ALT and this one is not)
+	const int li = ei - bi, lj = ej - bj, min_l = std::min(li, lj);
+	return (float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap;
+}
+inline bool much_lighter(const cs_flt_params_t &o, int wi, int wj) { return (float)wi < (float)wj * o.drop_ratio && wj - wi >= (o.min_seed_len << 1); }
+[[maybe_unused]] void overlap_scan_plain(const cs_flt_params_t &o, int n, const WRec *srt, const int *cb, const int *ce, const uint8_t *calt, std::vector<int> &keptv, std::vector<int> &first, std::vector<int> &nonov)
+{
+	keptv[0] = 3; nonov.push_back(0);
+	for (int i = 1; i < n; ++i) {
+		bool large = false; size_t k = 0;
+		for (; k < nonov.size(); ++k) {
+			const int j = nonov[k];
+			if (sig_overlap(o, cb[j], ce[j], calt[j] != 0, cb[i], ce[i], calt[i] != 0)) {
+				large = true;
+				if (first[(size_t)j] < 0) first[(size_t)j] = i;
+				if (much_lighter(o, srt[i].w, srt[j].w)) break;
+			}
+		}
+		if (k == nonov.size()) { nonov.push_back(i); keptv[(size_t)i] = large ? 2 : 3; }
+	}
+}
+// The same result without the quadratic part.  The kept chains are in descending weight, so "i is much lighter than kept chain k" holds for a
+// PREFIX of the list (both halves of the test are monotone in the kept chain's weight; drop_ratio >= 0).  Inside that prefix the scan stops
+// at the first significant overlap; behind it nothing can stop it, and all that is left to find is (a) whether any kept chain overlaps i --
+// the first hit answers -- and (b) the kept chains without a shadow yet that overlap i: those are kept in a list of their own, which a
+// chain leaves for good when it gets its shadow.  Among equal chains every kept chain is shadowed by the next one: the list holds one entry.
+struct ScanBuf { std::vector<int> kb, ke, kw, unset; std::vector<uint8_t> ka; };
+void overlap_scan(const cs_flt_params_t &o, int n, const WRec *srt, const int *cb, const int *ce, const uint8_t *calt, std::vector<int> &keptv, std::vector<int> &first, std::vector<int> &nonov, ScanBuf &B)
+{
+	if (!(o.drop_ratio >= 0.f)) { overlap_scan_plain(o, n, srt, cb, ce, calt, keptv, first, nonov); return; }
+	B.kb.clear(); B.ke.clear(); B.kw.clear(); B.ka.clear(); B.unset.clear();
+	auto keep = [&](int i, int mark) { B.unset.push_back((int)nonov.size()); nonov.push_back(i); B.kb.push_back(cb[i]); B.ke.push_back(ce[i]); B.kw.push_back(srt[i].w); B.ka.push_back(calt[i]); keptv[(size_t)i] = mark; };
+	keep(0, 3);
+	for (int i = 1; i < n; ++i) {
+		const int bi = cb[i], ei = ce[i], wi = srt[i].w; const bool ai = calt[i] != 0;
+		const int nk = (int)nonov.size();
+		int k = 0; bool stopped = false;
+		for (; k < nk && much_lighter(o, wi, B.kw[(size_t)k]); ++k)            // the prefix of much heavier kept chains
+			if (sig_overlap(o, B.kb[(size_t)k], B.ke[(size_t)k], B.ka[(size_t)k] != 0, bi, ei, ai)) { stopped = true; break; }
+		if (stopped) { const int j = nonov[(size_t)k]; if (first[(size_t)j] < 0) first[(size_t)j] = i; continue; }   // (its entry leaves `unset` when that list is next walked)
+		const int nw = k;                                                      // kept chains [nw, nk): overlaps are recorded, nothing stops the scan
+		bool large = false; size_t keep_u = 0;
+		for (size_t u = 0; u < B.unset.size(); ++u) {
+			const int q = B.unset[u], j = nonov[(size_t)q];
+			if (first[(size_t)j] >= 0) continue;                               // shadowed meanwhile
+			if (q >= nw && sig_overlap(o, B.kb[(size_t)q], B.ke[(size_t)q], B.ka[(size_t)q] != 0, bi, ei, ai)) { first[(size_t)j] = i; large = true; continue; }
+			B.unset[keep_u++] = q;
+		}
+		B.unset.resize(keep_u);
+		for (int q = nw; q < nk && !large; ++q) large = sig_overlap(o, B.kb[(size_t)q], B.ke[(size_t)q], B.ka[(size_t)q] != 0, bi, ei, ai);
+		keep(i, large ? 2 : 3);
+	}
+}
+
 void filter_range(const cs_chainer &C, const cs_flt_params_t &o, const cs_chain_result_t &in, const uint8_t *bases, const uint64_t *read_off, int64_t r0, int64_t r1, ReadOut &out)
 {
 	int8_t mat[25];
 	for (int i = 0, k = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) mat[k++] = (int8_t)(i == 4 || j == 4 ? -1 : i == j ? o.a : -o.b); // bwa_fill_scmat (bwalib/bwa.c:17-29)
 	const int64_t l_pac = C.ref.l_pac;
-	std::vector<WRec> srt; std::vector<int> keptv, first, order; std::vector<uint8_t> query, tseq; std::vector<int32_t> swbuf;
+	std::vector<WRec> srt; std::vector<int> keptv, first, order, nonov, cb, ce; std::vector<uint8_t> query, tseq, calt; std::vector<int32_t> swbuf; ScanBuf sc;
 	for (int64_t r = r0; r < r1; ++r) {
 		const uint64_t c0 = in.chain_off[r], c1 = in.chain_off[r + 1];
 		const int l_query = (int)(read_off[r + 1] - read_off[r]);
@@ -102,29 +166,22 @@ void filter_range(const cs_chainer &C, const cs_flt_params_t &o, const cs_chain_
 		order.clear();
 		if (n > 0) {
 			cs_klib_introsort((size_t)n, srt.data(), heavier);
-			auto beg = [&](int i) { return (int)seeds_of(srt[(size_t)i].idx)[0].qbeg; };
-			auto end = [&](int i) { const cs_seed_t &s = seeds_of(srt[(size_t)i].idx)[nseeds_of(srt[(size_t)i].idx) - 1]; return (int)(s.qbeg + s.len); };
-			auto alt = [&](int i) { return in.chains[c0 + (uint64_t)srt[(size_t)i].idx].is_alt != 0; };
-			keptv.assign((size_t)n, 0); first.assign((size_t)n, -1);
-			std::vector<int> &nonov = order; // (reused below for the output order) the chains kept so far that new ones are compared with
-			nonov.clear();
-			keptv[0] = 3; nonov.push_back(0);
-			for (int i = 1; i < n; ++i) {
-				bool large = false; size_t k = 0;
-				for (; k < nonov.size(); ++k) {
-					const int j = nonov[k];
-					const int b_max = std::max(beg(j), beg(i)), e_min = std::min(end(j), end(i));
-					if (e_min > b_max && (!alt(j) || alt(i))) { // an overlap on the read (not counted when the kept chain is ALT and this one is not)
-						const int li = end(i) - beg(i), lj = end(j) - beg(j), min_l = std::min(li, lj);
-						if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
-							large = true;
-							if (first[(size_t)j] < 0) first[(size_t)j] = i;
-							if ((float)srt[(size_t)i].w < (float)srt[(size_t)j].w * o.drop_ratio && srt[(size_t)j].w - srt[(size_t)i].w >= (o.min_seed_len << 1)) break;
-						}
-					}
-				}
-				if (k == nonov.size()) { nonov.push_back(i); keptv[(size_t)i] = large ? 2 : 3; }
+			// per chain, in the sorted order: its span on the read and whether it lies on an ALT contig
+			cb.resize((size_t)n); ce.resize((size_t)n); calt.resize((size_t)n);
+			for (int i = 0; i < n; ++i) {
+				const int idx = srt[(size_t)i].idx; const cs_seed_t *sd = seeds_of(idx); const cs_seed_t &last = sd[nseeds_of(idx) - 1];
+				cb[(size_t)i] = sd[0].qbeg; ce[(size_t)i] = last.qbeg + last.len; calt[(size_t)i] = in.chains[c0 + (uint64_t)idx].is_alt != 0;
 			}
+			keptv.assign((size_t)n, 0); first.assign((size_t)n, -1);
+			nonov.clear();                                                       // the chains kept so far, which new ones are compared with
+			overlap_scan(o, n, srt.data(), cb.data(), ce.data(), calt.data(), keptv, first, nonov, sc);
+#ifdef CS_FLT_SELFCHECK // (tools/sanitize_host.sh builds with it: the scan below against the loop as the reference writes it, on every read)
+			{
+				std::vector<int> k2((size_t)n, 0), f2((size_t)n, -1), n2;
+				overlap_scan_plain(o, n, srt.data(), cb.data(), ce.data(), calt.data(), k2, f2, n2);
+				if (k2 != keptv || f2 != first || n2 != nonov) { fprintf(stderr, "cs_chain_filter: overlap_scan differs from the plain loop (read %lld, %d chains)\n", (long long)r, n); abort(); }
+			}
+#endif
 			for (int j : nonov) if (first[(size_t)j] >= 0) keptv[(size_t)first[(size_t)j]] = 1;
 			int i = 0, extras = 0;
 			for (; i < n; ++i) { if (keptv[(size_t)i] == 0 || keptv[(size_t)i] == 3) continue; if (++extras >= o.max_chain_extend) break; }
