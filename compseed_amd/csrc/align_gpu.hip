@@ -380,13 +380,17 @@ __device__ void purge_read_global(const Args &A, int64_t r, uint8_t *pflag, int 
 		}
 	}
 }
-// the reads with more than 64 regions (reads inside repeats: hundreds to thousands of regions, and the walk is quadratic): a workgroup of four
-// waves per read, the read's regions and seeds staged in the LDS -- a step of the walk costs LDS round trips instead of HBM ones, 256 earlier
+// the reads with more than 64 regions (reads inside repeats: hundreds to thousands of regions, and the walk is quadratic): a workgroup of eight
+// waves per read, the read's regions and seeds staged in the LDS -- a step of the walk costs LDS round trips instead of HBM ones, 512 earlier
 // regions are looked at per round, the affordable gap (two divisions in double precision) comes from a table over the read's length, both
 // tests of a step are answered with ONE barrier (every wave casts its two votes, double-buffered), and the reads are handed out by a ticket
 // counter (a few reads of 2,000 regions are most of the work).  All 160 KB of a CU's LDS: one read per CU at a time.
 constexpr int PURGE_CAP = 3000, PURGE_GAPS = 1024;
-__global__ __launch_bounds__(256) void purge_big_kernel(const Args A, uint8_t *pflag)
+#ifndef CS_PURGE_THREADS
+#define CS_PURGE_THREADS 512
+#endif
+constexpr int PB = CS_PURGE_THREADS;   // threads of purge_big_kernel's workgroup
+__global__ __launch_bounds__(PB) void purge_big_kernel(const Args A, uint8_t *pflag)
 {
 	__shared__ PReg l_reg[PURGE_CAP];
 	__shared__ cs_seed_t l_seed[PURGE_CAP];
@@ -394,12 +398,12 @@ __global__ __launch_bounds__(256) void purge_big_kernel(const Args A, uint8_t *p
 	__shared__ uint8_t l_alive[PURGE_CAP];
 	__shared__ int32_t l_gap[PURGE_GAPS];
 	__shared__ unsigned long long l_ticket;
-	__shared__ uint32_t l_vote[2][4];
+	__shared__ uint32_t l_vote[2][PB / 64];
 	const cs_aln_params_t &o = A.o;
 	const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint64_t n_big = A.ctr[6];
 	unsigned long long my = 0;
-	for (int x = tid; x < PURGE_GAPS; x += 256) l_gap[x] = affordable_gap(o, x);
+	for (int x = tid; x < PURGE_GAPS; x += PB) l_gap[x] = affordable_gap(o, x);
 	for (;;) {
 		__syncthreads();                                            // (the previous read's last LDS reads are done)
 		if (tid == 0) l_ticket = atomicAdd(A.ctr + 7, 1ull);
@@ -411,22 +415,23 @@ __global__ __launch_bounds__(256) void purge_big_kernel(const Args A, uint8_t *p
 		if (g1 - g0 > (uint64_t)A.purge_cap) { if (tid < 64) purge_read_global(A, r, pflag, lane, my); continue; }
 		const int G = (int)(g1 - g0), l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
 		auto gap_of = [&](int x) { return (unsigned)x < (unsigned)PURGE_GAPS ? l_gap[x] : affordable_gap(o, x); };
-		for (int i = tid; i < G; i += 256) { PReg p; cs_seed_t s; int first; purge_load(A, g0, g0 + (uint64_t)i, p, s, first); l_reg[i] = p; l_seed[i] = s; l_first[i] = first; l_alive[i] = 1; }
+		for (int i = tid; i < G; i += PB) { PReg p; cs_seed_t s; int first; purge_load(A, g0, g0 + (uint64_t)i, p, s, first); l_reg[i] = p; l_seed[i] = s; l_first[i] = first; l_alive[i] = 1; }
 		__syncthreads();
 		for (int g = 1; g < G; ++g) {
 			const cs_seed_t sg = l_seed[g];
 			bool around = false, rival = false;
-			for (int i = tid; i < g && !around; i += 256) around = l_alive[i] && purge_around(sg, l_reg[i], l_query, gap_of);
-			for (int v = l_first[g] + tid; v < g && !rival; v += 256) rival = l_alive[v] && purge_rival(sg, l_seed[v]);
+			for (int i = tid; i < g && !around; i += PB) around = l_alive[i] && purge_around(sg, l_reg[i], l_query, gap_of);
+			for (int v = l_first[g] + tid; v < g && !rival; v += PB) rival = l_alive[v] && purge_rival(sg, l_seed[v]);
 			const uint32_t vote = (__ballot(around) ? 1u : 0u) | (__ballot(rival) ? 2u : 0u);
 			if (lane == 0) l_vote[g & 1][wv] = vote;
 			__syncthreads();
-			const uint32_t all = l_vote[g & 1][0] | l_vote[g & 1][1] | l_vote[g & 1][2] | l_vote[g & 1][3];
+			uint32_t all = 0;
+			for (int w = 0; w < PB / 64; ++w) all |= l_vote[g & 1][w];
 			if (all != 1u) continue;                                // not inside an earlier region, or defended by a rival
 			if (lane == 0) l_alive[g] = 0;                          // (every wave for itself: its own later reads follow its own write)
 			if (tid == 0) ++my;
 		}
-		for (int i = tid; i < G; i += 256) if (!l_alive[i]) { A.regs[g0 + (uint64_t)i].qb = -1; A.regs[g0 + (uint64_t)i].qe = -1; }
+		for (int i = tid; i < G; i += PB) if (!l_alive[i]) { A.regs[g0 + (uint64_t)i].qb = -1; A.regs[g0 + (uint64_t)i].qe = -1; }
 	}
 	if (lane == 0 && my) atomicAdd(A.ctr + 4, my);
 }
@@ -594,7 +599,7 @@ int cs_extend_chains_gpu_(cs_aligner_gpu **gp, int device, cs_extender_t *ext, c
 	HIP_TRYA(hipMemsetAsync(G.b[B_PFLAG].p, 0, (size_t)ns, s));
 	hipLaunchKernelGGL(csa::purge_kernel, grid(n * 64), dim3(256), 0, s, A);
 	lap("purge, light reads");
-	hipLaunchKernelGGL(csa::purge_big_kernel, dim3((unsigned)G.n_cu), dim3(256), 0, s, A, (uint8_t *)G.b[B_PFLAG].p);
+	hipLaunchKernelGGL(csa::purge_big_kernel, dim3((unsigned)G.n_cu), dim3(csa::PB), 0, s, A, (uint8_t *)G.b[B_PFLAG].p);
 	HIP_TRYA(hipGetLastError());
 	lap("purge");
 	regs.resize((size_t)ns);
