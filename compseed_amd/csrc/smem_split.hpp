@@ -1163,6 +1163,9 @@ __global__ __launch_bounds__(BLOCK, 5) void bwd_all_kernel(const SplitArgs A, co
 // first-survivor rule per call (the lanes of a call found by their key).  The kernel is VALU-bound: that is the point.
 // No dispenser and no atomics on the task side.
 struct WinPark { uint32_t r, code; int32_t te; uint16_t mk, key; };             // an end that passed the filter; key: 64-slot batch (10 bits) | slot (6)
+#ifndef CS_WIN_WAVES
+#define CS_WIN_WAVES 6
+#endif
 #ifndef CS_WIN0_WAVES
 #define CS_WIN0_WAVES 6
 #endif
@@ -1307,7 +1310,7 @@ __global__ __launch_bounds__(BLOCK, CS_WIN0_WAVES) void bwd_win0_kernel(const Sp
 
 // window scheme: ctrs[0] / ctrs[1] are the slot counters of the classes with up to 14 / 46 stored LEPs
 template <int BLOCK, bool COUNT>
-__global__ __launch_bounds__(BLOCK, 6) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
+__global__ __launch_bounds__(BLOCK, CS_WIN_WAVES) void bwd_win_kernel(const SplitArgs A, const BTask *bq, uint64_t n_tasks, unsigned long long *ctrs)
 {
 	if (*A.n_btasks == 0) return;
 	WaveOut O = {0, 0};
